@@ -1,0 +1,434 @@
+"""CPU oracle for the MissM-Benchmark forward/backward hot path.
+
+TEST INFRASTRUCTURE ONLY.  Nothing under ``missm_benchmark_amd/`` may import this
+module; only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s
+``cpu_baseline`` leg use it, and only as the checker / reported baseline.
+
+It is a plain-torch fp32 restatement (no ``transformers`` import, no ``nn.Module``)
+of the reference algorithm.  Every function cites the reference lines it follows
+(paths relative to /root/reference).  The arithmetic that the reference imports
+from third-party ``transformers`` (``CLIPAttention``, ``CLIPMLP``,
+``CLIPVisionEmbeddings``, ``CLIPTextEmbeddings``, ``_expand_mask``; call sites
+languagebind/image/modeling_image.py:11-12,69,71,463,602) is unpinned upstream
+(no requirements file); it is restated here in its transformers-4.3x form, which
+is the API the reference calls (``causal_attention_mask=`` kwarg).
+
+Pinning: ``oracle/make_golden.py`` runs the reference's own modules (imported
+from /root/reference with the shims of ``oracle/ref_shims.py``) and stock
+``transformers`` CLIP models built from local configs on seeded inputs, and
+writes ``tests/golden/*.pt``; ``tests/test_oracle_golden.py`` checks this file
+against those fixtures.  The reference itself has no tests / golden vectors
+(SURVEY.md section 4), so these captured outputs are the pin.
+
+Parameters are passed as flat ``dict[str, Tensor]`` keyed exactly like the
+reference ``state_dict()`` of one tower (e.g. ``encoder.layers.0.self_attn.q_proj.weight``,
+``pre_layrnorm.weight`` [sic]).  All functions are differentiable torch code, so
+``torch.autograd`` on the oracle yields the reference gradients.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, Optional, Sequence, Tuple
+
+import torch
+import torch.nn.functional as F
+
+Tensor = torch.Tensor
+Params = Dict[str, Tensor]
+
+
+# ----------------------------------------------------------------------------
+# configuration (shapes only; mirrors languagebind/image/configuration_image.py:70-105,181-232)
+# ----------------------------------------------------------------------------
+@dataclass
+class VisionCfg:
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    num_channels: int = 3
+    image_size: int = 224
+    patch_size: int = 16
+    layer_norm_eps: float = 1e-5
+    hidden_act: str = "quick_gelu"
+    add_time_attn: bool = False
+    num_frames: int = 1
+    # image/audio/depth/thermal modeling files keep a temporal MLP in the time branch
+    # (image/modeling_image.py:83-84,129-134); the video file removed it (video/modeling_video.py:189-190,235-240)
+    temporal_mlp: bool = False
+
+    @property
+    def num_patches(self) -> int:
+        return (self.image_size // self.patch_size) ** 2
+
+    @property
+    def seq_len(self) -> int:
+        return self.num_patches + 1
+
+
+@dataclass
+class TextCfg:
+    vocab_size: int = 49408
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    max_position_embeddings: int = 77
+    layer_norm_eps: float = 1e-5
+    hidden_act: str = "quick_gelu"
+    add_time_attn: bool = False  # configuration_image.py:105 hard-codes this
+    num_frames: int = 1
+    temporal_mlp: bool = False
+
+
+# reference: src/model/baseline.py:8 ; depth/thermal are this build's documented extension
+#  leaving codes 0-4 untouched.
+MISSING_TYPE_INDEX = {"language": 1, "video": 2, "audio": 3, "image": 4, "depth": 5, "thermal": 6}
+
+
+# ----------------------------------------------------------------------------
+# third-party arithmetic restated (transformers 4.3x CLIP)
+# ----------------------------------------------------------------------------
+def activation(x: Tensor, name: str) -> Tensor:
+    """``ACT2FN[config.hidden_act]``; default quick_gelu = x * sigmoid(1.702 x)
+    (configuration_image.py:191; transformers/activations.py QuickGELUActivation)."""
+    if name == "quick_gelu":
+        return x * torch.sigmoid(1.702 * x)
+    if name == "gelu":
+        return F.gelu(x)
+    raise ValueError(f"unsupported hidden_act {name!r}")
+
+
+def layer_norm(x: Tensor, p: Params, prefix: str, eps: float) -> Tensor:
+    """``nn.LayerNorm(embed_dim, eps)`` sites: image/modeling_image.py:70,72,82,84,465,604,606."""
+    return F.layer_norm(x, (x.shape[-1],), p[prefix + ".weight"], p[prefix + ".bias"], eps)
+
+
+def clip_attention(x: Tensor, p: Params, prefix: str, num_heads: int,
+                   attention_mask: Optional[Tensor] = None,
+                   causal_attention_mask: Optional[Tensor] = None) -> Tensor:
+    """``CLIPAttention.forward`` (third-party; called at image/modeling_image.py:121-126,140-145).
+
+    q = (x Wq^T + bq) * hd^-1/2 ; scores = q k^T (+ causal) (+ padding) ; softmax over keys ;
+    out = (P v) Wo^T + bo.  Masks are additive [B,1,S,S] with finfo.min at blocked positions.
+    """
+    bsz, tgt, dim = x.shape
+    hd = dim // num_heads
+    scale = hd ** -0.5
+    q = F.linear(x, p[prefix + ".q_proj.weight"], p[prefix + ".q_proj.bias"]) * scale
+    k = F.linear(x, p[prefix + ".k_proj.weight"], p[prefix + ".k_proj.bias"])
+    v = F.linear(x, p[prefix + ".v_proj.weight"], p[prefix + ".v_proj.bias"])
+
+    def heads(t: Tensor) -> Tensor:
+        return t.view(bsz, tgt, num_heads, hd).transpose(1, 2)  # [B,H,S,hd]
+
+    q, k, v = heads(q), heads(k), heads(v)
+    w = torch.matmul(q, k.transpose(-1, -2))  # [B,H,S,S]
+    if causal_attention_mask is not None:
+        w = w + causal_attention_mask
+    if attention_mask is not None:
+        w = w + attention_mask
+    w = torch.softmax(w, dim=-1)
+    o = torch.matmul(w, v)  # [B,H,S,hd]
+    o = o.transpose(1, 2).reshape(bsz, tgt, dim)
+    return F.linear(o, p[prefix + ".out_proj.weight"], p[prefix + ".out_proj.bias"])
+
+
+def clip_mlp(x: Tensor, p: Params, prefix: str, act: str) -> Tensor:
+    """``CLIPMLP.forward`` (third-party; called at image/modeling_image.py:150): fc2(act(fc1(x)))."""
+    h = F.linear(x, p[prefix + ".fc1.weight"], p[prefix + ".fc1.bias"])
+    h = activation(h, act)
+    return F.linear(h, p[prefix + ".fc2.weight"], p[prefix + ".fc2.bias"])
+
+
+def make_causal_mask(seq: int, dtype: torch.dtype) -> Tensor:
+    """``_make_causal_mask`` image/modeling_image.py:441-455: finfo.min strictly above the diagonal."""
+    m = torch.full((seq, seq), torch.finfo(dtype).min, dtype=dtype)
+    return torch.triu(m, diagonal=1)[None, None]
+
+
+def expand_padding_mask(attention_mask: Tensor, dtype: torch.dtype) -> Tensor:
+    """``_expand_mask`` (third-party, used at image/modeling_image.py:499-501):
+    [B,S] 1/0 -> additive [B,1,S,S] with finfo.min on masked key columns."""
+    bsz, src = attention_mask.shape
+    expanded = attention_mask[:, None, None, :].expand(bsz, 1, src, src).to(dtype)
+    inverted = 1.0 - expanded
+    return inverted.masked_fill(inverted.to(torch.bool), torch.finfo(dtype).min)
+
+
+# ----------------------------------------------------------------------------
+# encoder layer / encoder  (image/modeling_image.py:86-158,352-437; video/modeling_video.py:192-264)
+# ----------------------------------------------------------------------------
+def encoder_layer(h: Tensor, p: Params, prefix: str, cfg, attention_mask=None, causal_attention_mask=None) -> Tensor:
+    """``CLIPEncoderLayer.forward``.  ``h`` is [(b t), n, d] for vision, [b, s, d] for text."""
+    nh = cfg.num_attention_heads
+    eps = cfg.layer_norm_eps
+    if cfg.add_time_attn:
+        bt, n, d = h.shape
+        t = cfg.num_frames
+        b = bt // t
+        if t != 1:  # time embed (:110-114)
+            hh = h.view(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
+            hh = hh + p[prefix + ".temporal_embedding"][:, :t, :]
+            h = hh.view(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)
+        # time attn (:117-127)
+        residual = h
+        hh = h.view(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
+        hh = layer_norm(hh, p, prefix + ".temporal_layer_norm1", eps)
+        hh = clip_attention(hh, p, prefix + ".temporal_attn", nh, attention_mask, causal_attention_mask)
+        h = residual + hh.view(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)
+        if cfg.temporal_mlp:  # image-family only (:129-134)
+            residual = h
+            hh = h.view(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
+            hh = layer_norm(hh, p, prefix + ".temporal_layer_norm2", eps)
+            hh = clip_mlp(hh, p, prefix + ".temporal_mlp", cfg.hidden_act)
+            h = residual + hh.view(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)
+    # spatial attn (:137-146)
+    residual = h
+    x = layer_norm(h, p, prefix + ".layer_norm1", eps)
+    x = clip_attention(x, p, prefix + ".self_attn", nh, attention_mask, causal_attention_mask)
+    h = residual + x
+    # mlp (:148-151)
+    residual = h
+    x = layer_norm(h, p, prefix + ".layer_norm2", eps)
+    x = clip_mlp(x, p, prefix + ".mlp", cfg.hidden_act)
+    return residual + x
+
+
+def encoder(h: Tensor, p: Params, cfg, attention_mask=None, causal_attention_mask=None) -> Tensor:
+    """``CLIPEncoder.forward`` image/modeling_image.py:400-428 (no grad-checkpointing, hooks off)."""
+    for i in range(cfg.num_hidden_layers):
+        h = encoder_layer(h, p, f"encoder.layers.{i}", cfg, attention_mask, causal_attention_mask)
+    return h
+
+
+# ----------------------------------------------------------------------------
+# towers
+# ----------------------------------------------------------------------------
+def vision_embeddings(pixel_values: Tensor, p: Params, cfg: VisionCfg) -> Tensor:
+    """``CLIPVisionEmbeddings.forward`` video/modeling_video.py:42-51 (third-party twin for the other towers):
+    bias-free conv k=stride=patch -> flatten -> cat CLS -> + position embedding."""
+    n = pixel_values.shape[0]
+    pe = F.conv2d(pixel_values, p["embeddings.patch_embedding.weight"], None, stride=cfg.patch_size)
+    pe = pe.flatten(2).transpose(1, 2)  # [N, P, d]
+    cls = p["embeddings.class_embedding"].expand(n, 1, -1)
+    x = torch.cat([cls, pe], dim=1)
+    return x + p["embeddings.position_embedding.weight"][None, : x.shape[1]]
+
+
+def vision_tower(pixel_values: Tensor, p: Params, cfg: VisionCfg) -> Tuple[Tensor, Tensor]:
+    """``CLIPVisionTransformer.forward`` image/modeling_image.py:610-672 / video/modeling_video.py:723-784.
+    Returns (last_hidden_state [(B T), S, d], pooled [B, d])."""
+    if pixel_values is None:
+        raise ValueError("You have to specify pixel_values")
+    if pixel_values.dim() == 7:  # :630-634
+        b_new, pair_new, T, bs_new, c, hh, ww = pixel_values.shape
+        B = b_new * pair_new * bs_new
+        pixel_values = pixel_values.reshape(B * T, c, hh, ww)
+    elif pixel_values.dim() == 5:  # :636-639  'b c t h w -> (b t) c h w'
+        B, c, T, hh, ww = pixel_values.shape
+        pixel_values = pixel_values.permute(0, 2, 1, 3, 4).reshape(B * T, c, hh, ww)
+    else:
+        B, T = pixel_values.shape[0], 1
+    h = vision_embeddings(pixel_values, p, cfg)
+    # PatchDropout (:30-63) is the identity at force_patch_dropout == 0 (default) and in eval.
+    h = layer_norm(h, p, "pre_layrnorm", cfg.layer_norm_eps)
+    h = encoder(h, p, cfg)
+    pooled = layer_norm(h[:, 0, :], p, "post_layernorm", cfg.layer_norm_eps)
+    pooled = pooled.reshape(B, T, -1).mean(1)  # :662
+    return h, pooled
+
+
+def text_tower(input_ids: Tensor, attention_mask: Optional[Tensor], p: Params, cfg: TextCfg) -> Tuple[Tensor, Tensor]:
+    """``CLIPTextTransformer.forward`` image/modeling_image.py:469-532.
+    Returns (last_hidden_state [B,S,d] after final LN, pooled [B,d] at the EOT position)."""
+    if input_ids is None:
+        raise ValueError("You have to specify input_ids")
+    input_ids = input_ids.view(-1, input_ids.shape[-1])
+    bsz, seq = input_ids.shape
+    tok = p["embeddings.token_embedding.weight"][input_ids]          # CLIPTextEmbeddings (third-party)
+    h = tok + p["embeddings.position_embedding.weight"][None, :seq]
+    causal = make_causal_mask(seq, h.dtype)
+    pad = expand_padding_mask(attention_mask, h.dtype) if attention_mask is not None else None
+    h = encoder(h, p, cfg, attention_mask=pad, causal_attention_mask=causal)
+    h = layer_norm(h, p, "final_layer_norm", cfg.layer_norm_eps)
+    eot = input_ids.to(torch.int).argmax(dim=-1)                      # :519-522
+    pooled = h[torch.arange(bsz), eot]
+    return h, pooled
+
+
+# ----------------------------------------------------------------------------
+# bundle + fusion + loss
+# ----------------------------------------------------------------------------
+def bundle_embed(pooled: Tensor, proj_weight: Tensor, logit_scale: Optional[Tensor], modality: str,
+                 use_temp: bool = True) -> Tensor:
+    """``LanguageBind.forward`` body, languagebind/__init__.py:78-84:
+    bias-free projection -> / L2 norm -> * exp(logit_scale) unless language."""
+    v = F.linear(pooled, proj_weight)
+    v = v / v.norm(p=2, dim=-1, keepdim=True)
+    if use_temp and modality != "language":
+        v = v * logit_scale.exp()
+    return v
+
+
+def head_forward(x: Tensor, fp: Params, prefix: str = "head.head") -> Tensor:
+    """``Head`` src/model/baseline.py:27-39 with Dropout in eval / p=0 (identity)."""
+    x = F.linear(x, fp[prefix + ".0.weight"], fp[prefix + ".0.bias"])
+    x = F.relu(x)
+    return F.linear(x, fp[prefix + ".3.weight"], fp[prefix + ".3.bias"])
+
+
+def fusion_sum(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+               codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_sum.forward`` src/model/baseline.py:52-61: per-modality Linear, zero rows whose
+    missing code matches, sum, LayerNorm(eps 1e-5), Head."""
+    z = None
+    for m in modality_types:
+        d = F.linear(emb[m], fp[f"modal_proj.{m}.weight"], fp[f"modal_proj.{m}.bias"])
+        d = torch.where((missing_index == codes[m])[:, None], torch.zeros_like(d), d)
+        z = d if z is None else z + d
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
+def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
+    """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
+    return F.cross_entropy(logits, labels)
+
+
+def finetune_forward(data: Dict[str, Dict[str, Tensor]], missing_index: Tensor, tower_params: Dict[str, Params],
+                     tower_cfgs: Dict[str, object], proj: Dict[str, Tensor], scales: Dict[str, Tensor],
+                     fusion_params: Params, modality_types: Sequence[str]) -> Tuple[Tensor, Dict[str, Tensor]]:
+    """``finetune_model.forward`` src/model/baseline.py:450-453 with fusion_type == 'sum'.
+    Returns (logits, bundle embeddings)."""
+    emb: Dict[str, Tensor] = {}
+    for m, inputs in data.items():
+        if m == "language":
+            _, pooled = text_tower(inputs["input_ids"], inputs.get("attention_mask"), tower_params[m], tower_cfgs[m])
+        else:
+            _, pooled = vision_tower(inputs["pixel_values"], tower_params[m], tower_cfgs[m])
+        emb[m] = bundle_embed(pooled, proj[m], scales.get(m), m)
+    return fusion_sum(emb, missing_index, fusion_params, modality_types), emb
+
+
+# ----------------------------------------------------------------------------
+# Adam (torch.optim.Adam defaults, train_ddp.py:205): one step on a flat tensor
+# ----------------------------------------------------------------------------
+def adam_step(p: Tensor, g: Tensor, m: Tensor, v: Tensor, step: int, lr: float, beta1: float = 0.9,
+              beta2: float = 0.999, eps: float = 1e-8, weight_decay: float = 0.0) -> None:
+    """In-place single Adam update identical to ``torch.optim.Adam`` (non-amsgrad, L2 weight decay)."""
+    if weight_decay != 0.0:
+        g = g + weight_decay * p
+    m.mul_(beta1).add_(g, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-lr / bc1)
+
+
+# ----------------------------------------------------------------------------
+# seeded synthetic parameters / inputs  (the build's own recipe)
+# ----------------------------------------------------------------------------
+def _normal(shape, std: float, gen: torch.Generator) -> Tensor:
+    return torch.randn(shape, generator=gen, dtype=torch.float32) * std
+
+
+def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
+    """Deterministic per-tensor init with the std's of ``CLIPPreTrainedModel._init_weights``
+    (image/modeling_image.py:179-230) but an RNG order owned by this build.  Biases and LN
+    shifts get small non-zero values so that bias/shift paths are exercised by parity tests."""
+    gen = torch.Generator().manual_seed(seed)
+    d, f, L = cfg.hidden_size, cfg.intermediate_size, cfg.num_hidden_layers
+    p: Params = {}
+    in_std = d ** -0.5 * (2 * L) ** -0.5
+    out_std = d ** -0.5
+    fc_std = (2 * d) ** -0.5
+
+    def ln(name):
+        p[name + ".weight"] = 1.0 + _normal((d,), 0.02, gen)
+        p[name + ".bias"] = _normal((d,), 0.02, gen)
+
+    def attn(name):
+        for w in ("q_proj", "k_proj", "v_proj"):
+            p[f"{name}.{w}.weight"] = _normal((d, d), in_std, gen)
+            p[f"{name}.{w}.bias"] = _normal((d,), 0.02, gen)
+        p[f"{name}.out_proj.weight"] = _normal((d, d), out_std, gen)
+        p[f"{name}.out_proj.bias"] = _normal((d,), 0.02, gen)
+
+    def mlp(name):
+        p[f"{name}.fc1.weight"] = _normal((f, d), fc_std, gen)
+        p[f"{name}.fc1.bias"] = _normal((f,), 0.02, gen)
+        p[f"{name}.fc2.weight"] = _normal((d, f), in_std, gen)
+        p[f"{name}.fc2.bias"] = _normal((d,), 0.02, gen)
+
+    if kind == "vision":
+        p["embeddings.class_embedding"] = _normal((d,), d ** -0.5, gen)
+        p["embeddings.patch_embedding.weight"] = _normal((d, cfg.num_channels, cfg.patch_size, cfg.patch_size), 0.02, gen)
+        p["embeddings.position_embedding.weight"] = _normal((cfg.seq_len, d), 0.02, gen)
+        ln("pre_layrnorm")
+    else:
+        p["embeddings.token_embedding.weight"] = _normal((cfg.vocab_size, d), 0.02, gen)
+        p["embeddings.position_embedding.weight"] = _normal((cfg.max_position_embeddings, d), 0.02, gen)
+    for i in range(L):
+        pre = f"encoder.layers.{i}"
+        if cfg.add_time_attn:
+            p[pre + ".temporal_embedding"] = _normal((1, cfg.num_frames, d), d ** -0.5, gen)
+            attn(pre + ".temporal_attn")
+            ln(pre + ".temporal_layer_norm1")
+            if cfg.temporal_mlp:
+                mlp(pre + ".temporal_mlp")
+                ln(pre + ".temporal_layer_norm2")
+        attn(pre + ".self_attn")
+        ln(pre + ".layer_norm1")
+        mlp(pre + ".mlp")
+        ln(pre + ".layer_norm2")
+    ln("post_layernorm" if kind == "vision" else "final_layer_norm")
+    return p
+
+
+def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
+                       seed: int) -> Params:
+    """Seeded init for ``modal_sum`` + ``Head`` (src/model/baseline.py:27-50) parameter names."""
+    gen = torch.Generator().manual_seed(seed)
+    fp: Params = {}
+    for m in modality_types:
+        fp[f"modal_proj.{m}.weight"] = _normal((fusion_dim, feature_dims), feature_dims ** -0.5, gen)
+        fp[f"modal_proj.{m}.bias"] = _normal((fusion_dim,), 0.02, gen)
+    fp["norm.weight"] = 1.0 + _normal((fusion_dim,), 0.02, gen)
+    fp["norm.bias"] = _normal((fusion_dim,), 0.02, gen)
+    fp["head.head.0.weight"] = _normal((fusion_dim, fusion_dim), fusion_dim ** -0.5, gen)
+    fp["head.head.0.bias"] = _normal((fusion_dim,), 0.02, gen)
+    fp["head.head.3.weight"] = _normal((num_classes, fusion_dim), fusion_dim ** -0.5, gen)
+    fp["head.head.3.bias"] = _normal((num_classes,), 0.02, gen)
+    return fp
+
+
+def synth_text_batch(batch: int, ctx: int, seed: int, vocab: int = 49408) -> Tuple[Tensor, Tensor]:
+    """Config-2 text recipe: ids uniform in [1000,40000), BOS 49406 first,
+    EOS (= pad, the max id) at len-1 and beyond, len ~ U{8..ctx}."""
+    gen = torch.Generator().manual_seed(seed)
+    bos, eos = vocab - 2, vocab - 1
+    lo, hi = (1000, 40000) if vocab > 40000 else (1, max(2, vocab - 2))
+    ids = torch.randint(lo, hi, (batch, ctx), generator=gen)
+    lens = torch.randint(min(8, ctx), ctx + 1, (batch,), generator=gen)
+    pos = torch.arange(ctx)[None]
+    ids[:, 0] = bos
+    ids = torch.where(pos >= (lens[:, None] - 1), torch.full_like(ids, eos), ids)
+    mask = (pos < lens[:, None]).to(torch.int64)
+    return ids, mask
+
+
+def synth_missing_index(batch: int, modality_types: Sequence[str], ratio: float, seed: int,
+                        codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``simulate_missing_modality`` src/utils/generate_missing.py:8-40, 'mixed' mode restated bit-exactly:
+    ``int(n*ratio)`` samples drawn by ``random.sample`` after ``random.seed(seed)``, each given a code
+    drawn by ``random.choice`` over the present modalities' codes; all other samples 0."""
+    import random
+    rng = random.Random(seed)
+    pool = [codes[m] for m in modality_types]
+    out = [0] * batch
+    for idx in rng.sample(range(batch), int(batch * ratio)):
+        out[idx] = rng.choice(pool)
+    return torch.tensor(out, dtype=torch.int64)

@@ -1,0 +1,140 @@
+"""Pin the CPU oracle against fixtures produced by RUNNING the reference (oracle/make_golden.py).
+
+CPU-only; these are the `-m "not gpu"` checks that the oracle restates the reference."""
+import torch
+
+import missm_oracle as O
+from conftest import load_golden
+
+TOL = 5e-6  # CPU fp32 vs CPU fp32 (different op orderings only)
+
+
+def _vision_inputs(fix, cfg):
+    if "pixel_values" in fix:
+        return fix["pixel_values"]
+    g = torch.Generator().manual_seed(fix["seed_x"])
+    shape = (fix["batch"], cfg.num_channels) + ((cfg.num_frames,) if cfg.num_frames > 1 else ()) + (cfg.image_size, cfg.image_size)
+    return torch.randn(*shape, generator=g)
+
+
+def _check_vision(name):
+    fix = load_golden(name)
+    cfg = O.VisionCfg(**fix["cfg"])
+    params = fix.get("params") or O.init_tower_params(cfg, fix["seed_w"])
+    params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    x = _vision_inputs(fix, cfg)
+    last, pooled = O.vision_tower(x, params, cfg)
+    assert (pooled - fix["pooled"]).abs().max() < TOL
+    if "last_hidden_state" in fix:
+        assert (last - fix["last_hidden_state"]).abs().max() < TOL
+    else:
+        assert (last[:, :4, :64] - fix["last_hidden_slice"]).abs().max() < TOL
+    if "grads" in fix:
+        if "cot_pooled" in fix:
+            cp, ch = fix["cot_pooled"], fix["cot_last"]
+        else:
+            cp = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(fix["seed_x"] + 100))
+            ch = torch.randn(last.shape, generator=torch.Generator().manual_seed(fix["seed_x"] + 101)) * 0.1
+        ((pooled * cp).sum() + (last * ch).sum()).backward()
+        for k, g in fix["grads"].items():
+            mine = params[k].grad
+            if mine.shape != g.shape:
+                mine = mine[:64, :64] if mine.dim() == 2 else mine[:64]
+            scale = max(1.0, float(g.abs().max()))
+            assert (mine - g).abs().max() < 2e-5 * scale, k
+
+
+def test_vision_tiny():
+    _check_vision("vision_tiny")
+
+
+def test_video_tiny_time_attention():
+    _check_vision("video_tiny")
+
+
+def test_vision_s197_hd64():
+    _check_vision("vision_s197")
+
+
+def test_vitb16_config1():
+    """BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224, CPU."""
+    torch.set_grad_enabled(False)
+    try:
+        fix = load_golden("vitb16_config1")
+        cfg = O.VisionCfg(**fix["cfg"])
+        params = O.init_tower_params(cfg, fix["seed_w"])
+        last, pooled = O.vision_tower(_vision_inputs(fix, cfg), params, cfg)
+        assert (pooled - fix["pooled"]).abs().max() < 1e-5
+        assert (last[:, :4, :64] - fix["last_hidden_slice"]).abs().max() < 1e-5
+    finally:
+        torch.set_grad_enabled(True)
+
+
+def test_text_tiny_causal_padding_eot():
+    fix = load_golden("text_tiny")
+    cfg = O.TextCfg(**fix["cfg"])
+    params = {k: v.clone().requires_grad_(True) for k, v in fix["params"].items()}
+    ids, mask = fix["input_ids"], fix["attention_mask"]
+    i2, m2 = O.synth_text_batch(ids.shape[0], ids.shape[1], 8, vocab=cfg.vocab_size)
+    assert torch.equal(i2, ids) and torch.equal(m2, mask)
+    last, pooled = O.text_tower(ids, mask, params, cfg)
+    valid = mask.bool()
+    assert (last - fix["last_hidden_state"])[valid].abs().max() < TOL
+    assert (pooled - fix["pooled"]).abs().max() < TOL
+    assert (pooled - fix["pooled_ref_encoder"]).abs().max() < TOL
+    (pooled * fix["cot_pooled"]).sum().backward()
+    for k, g in fix["grads"].items():
+        assert (params[k].grad - g).abs().max() < 2e-5 * max(1.0, float(g.abs().max())), k
+
+
+def test_text_requires_input_ids():
+    import pytest
+    with pytest.raises(ValueError, match="You have to specify input_ids"):
+        O.text_tower(None, None, {}, O.TextCfg())
+    with pytest.raises(ValueError, match="You have to specify pixel_values"):
+        O.vision_tower(None, {}, O.VisionCfg())
+
+
+def test_fusion_sum_and_loss():
+    fix = load_golden("fusion_sum")
+    assert {k: O.MISSING_TYPE_INDEX[k] for k in fix["missing_type_index"]} == fix["missing_type_index"]
+    fp = {k: v.clone().requires_grad_(True) for k, v in fix["params"].items()}
+    emb = {m: e.clone().requires_grad_(True) for m, e in fix["emb"].items()}
+    logits = O.fusion_sum(emb, fix["missing_index"], fp, fix["modality_types"])
+    assert (logits - fix["logits"]).abs().max() < TOL
+    loss = O.cross_entropy(logits, fix["labels"])
+    assert abs(float(loss.detach()) - float(fix["loss"])) < TOL
+    loss.backward()
+    for m in emb:
+        assert (emb[m].grad - fix["emb_grads"][m]).abs().max() < TOL
+    for k, g in fix["grads"].items():
+        assert (fp[k].grad - g).abs().max() < TOL, k
+
+
+def test_bundle_project_normalise_scale():
+    fix = load_golden("bundle")
+    for m, ref in fix["out"].items():
+        out = O.bundle_embed(fix["pooled"][m], fix["proj"][m], torch.tensor(fix["logit_scale"]), m)
+        assert (out - ref).abs().max() < TOL
+    # language is not temperature-scaled
+    assert abs(float(fix["out"]["language"].norm(dim=-1).mean()) - 1.0) < 1e-5
+
+
+def test_missing_index_bit_exact():
+    for case in load_golden("missing_index"):
+        mine = O.synth_missing_index(case["n"], case["modal"], case["ratio"], case["seed"])
+        assert torch.equal(mine, case["index"])
+
+
+def test_adam_matches_torch_optim():
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(1000, generator=g)
+    ref = p.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    for step in range(1, 4):
+        grad = torch.randn(1000, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        O.adam_step(p, grad, m, v, step, 1e-3)
+    assert (p - ref.detach()).abs().max() < 1e-6
