@@ -1,0 +1,129 @@
+/* missm_hip.h - C ABI of the MI355X (gfx950) kernels behind the MissM-Benchmark forward/backward hot path.
+ *
+ * The reference (Fieldhunter/MissM-Benchmark) has no native code and no FFI: its hot path is PyTorch modules
+ * (`languagebind.LanguageBind`, `src.model.baseline.finetune_model`) whose arithmetic PyTorch dispatches to
+ * vendor kernels.  This library is what a binding for that path would bind instead; every entry point names the
+ * reference call site whose dispatched kernels it replaces.  The Python host side (missm_benchmark_amd/_lib.py)
+ * binds it with ctypes; INTEGRATION.md shows the stub a reference maintainer would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer (HIP), plain `void*` / `float*` / `int*`; no framework types
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream); all work is enqueued, nothing syncs
+ *   - `dtype`: 0 = fp32, 1 = bf16 (the activation / GEMM-operand type "T"); the residual stream, LayerNorm
+ *     statistics, all parameters' master copies, gradients of parameters and the fusion tail are always fp32
+ *   - return value: MISSM_OK (0) or a negative MISSM_ERR_* code; missm_last_error() returns a thread-local,
+ *     NUL-terminated description of the last failure on the calling thread
+ *   - kernels borrow the buffers for the duration of the enqueued work only (the caller owns all memory)
+ */
+#ifndef MISSM_HIP_H
+#define MISSM_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MISSM_OK 0
+#define MISSM_ERR_INVALID (-1)
+#define MISSM_ERR_LAUNCH (-2)
+#define MISSM_ERR_NO_DEVICE (-3)
+
+#define MISSM_F32 0
+#define MISSM_BF16 1
+
+/* epilogue activations of missm_gemm_nt */
+#define MISSM_ACT_NONE 0
+#define MISSM_ACT_QGELU 1   /* x * sigmoid(1.702 x)  (hidden_act default, configuration_image.py:191) */
+#define MISSM_ACT_GELU 2    /* erf gelu */
+#define MISSM_ACT_DQGELU 3  /* multiply by quick_gelu'(aux_in) */
+#define MISSM_ACT_DGELU 4   /* multiply by gelu'(aux_in) */
+#define MISSM_ACT_RELU 5
+
+const char* missm_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int missm_abi_version(void);
+/* Number of visible HIP devices (0 when none); never initialises a device context. */
+int missm_device_count(void);
+
+/* C[M,N] = alpha * A[M,K] . B[N,K]^T (+bias[N]) -> act -> (+resid) ; A, B of type `dtype`, fp32 accumulate (MFMA).
+ * Output is `dtype` unless out_f32.  aux_out receives the pre-activation (for the backward), aux_in supplies it.
+ * Replaces: nn.Linear inside CLIPAttention q/k/v/out_proj and CLIPMLP fc1/fc2
+ * (languagebind/image/modeling_image.py:69,71,140-151), the patch-embed conv as a GEMM over unfolded patches
+ * (languagebind/video/modeling_video.py:29-35,45-46) and all their autograd GEMMs. */
+int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, float alpha,
+                  const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act, int out_f32,
+                  int accumulate, int dtype, void* stream);
+
+/* out[C, ldo] = in[R, C]^T zero-padded to ldo columns; optional colsum[C] += column sums (bias gradient). */
+int missm_transpose_pad(const void* in, void* out, int R, int C, int ld, int ldo, float* colsum, int dtype, void* stream);
+/* out[(row / div) % mod][c] += in[row][c]  (position / temporal embedding and bias gradients). */
+int missm_colsum(const void* in, float* out, int R, int C, int ld, int div, int mod, int dtype, void* stream);
+/* fp32 master weight [R,C] -> `dtype` shadow dst[R,C] and/or transposed shadow dst_t[C,R] (either may be NULL). */
+int missm_cast_weight(const float* src, void* dst, void* dst_t, int R, int C, int dtype, void* stream);
+
+/* LayerNorm over fp32 rows.  Input row = x[row * in_mul + in_off[row]] (row gather for CLS / EOT pooling);
+ * if `add` is given, add[(row / add_div) % add_mod] is added first and the sum written back to x_wb
+ * (temporal_embedding).  Saves mean / rstd.  Replaces nn.LayerNorm at image/modeling_image.py:70,72,82,465,604,606,
+ * src/model/baseline.py:48. */
+int missm_layernorm_fwd(const float* x, float* x_wb, const float* add, int add_div, int add_mod, int in_mul, const int* in_off,
+                        const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int cols, float eps,
+                        int out_dtype, void* stream);
+/* dx (fp32, same row mapping as x; += when accumulate) ; dgamma/dbeta atomically accumulated (caller zeroes).
+ * dy row = row / dy_div, scaled by dy_scale (mean over frames). */
+int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
+                        const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate, float* dgamma,
+                        float* dbeta, int rows, int cols, int dy_dtype, void* stream);
+/* out[b] = mean_t in[b*T + t]   (pooled_output.reshape(B, T, -1).mean(1), image/modeling_image.py:662). */
+int missm_mean_rows(const float* in, float* out, int B, int T, int cols, void* stream);
+
+/* Fused softmax(Q K^T * scale + masks) V for all heads of all sequences, reading the fused [rows, 3*H*hd] QKV matrix.
+ * Token j of sequence q is row (q / seq_div) * seq_outer + (q % seq_div) * seq_inner + j * tok_stride.
+ * causal != 0 masks keys j > i; key_mask[nseq, L] (0 = masked) is the padding mask.  lse[nseq, H, L] is saved.
+ * Replaces CLIPAttention's bmm/softmax/bmm (third-party; called at image/modeling_image.py:121-126,140-145). */
+int missm_attention_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int head_dim, int ld, int ldo,
+                        int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal, const int* key_mask, float scale,
+                        int dtype, void* stream);
+int missm_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int nseq, int L, int H, int head_dim,
+                        int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal,
+                        const int* key_mask, float scale, int dtype, void* stream);
+
+/* Patch unfold: pixels fp32 (frame n = (b, t): base b*stride_b + t*stride_t, channel stride_c, row-major HxW) ->
+ * A[n*P + p, c*ps*ps + ky*ps + kx] of type `dtype` (the conv weight's .view(d, -1) order). */
+int missm_unfold_patches(const float* pixels, void* out, int B, int T, int C, int H, int W, int ps, long stride_b,
+                         long stride_t, long stride_c, int dtype, void* stream);
+/* x[n, s, :] = (s == 0 ? cls : patches[n*(S-1) + s-1]) + pos[s]   (CLIPVisionEmbeddings, video/modeling_video.py:48-50). */
+int missm_embed_assemble(const void* patches, const float* cls, const float* pos, float* x, int N, int S, int d, int dtype,
+                         void* stream);
+/* h[b, s, :] = tok[ids[b, s]] + pos[s]  (CLIPTextEmbeddings, third-party; image/modeling_image.py:494). */
+int missm_token_embed_fwd(const long* ids, const float* tok, const float* pos, float* h, int B, int S, int d, void* stream);
+/* dtok[ids[b,s]] += dh[b,s] (atomic), dpos[s] += sum_b dh[b,s]. */
+int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* dpos, int B, int S, int d, void* stream);
+/* eot[b] = argmax_s ids[b, s] (first occurrence), image/modeling_image.py:519-522. */
+int missm_argmax_rows(const long* ids, int* out, int B, int S, void* stream);
+
+/* y[b, o] = sum_i x[b, i] w[o, i] (+ bias[o]) -> optional ReLU ; all fp32 (projection / fusion tail).
+ * row_code/code: rows with row_code[b] == code produce 0 (modality missing, src/model/baseline.py:57);
+ * accumulate: y += (sum over modalities). */
+int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
+                           const long* row_code, long code, int accumulate, void* stream);
+/* dx[b,i] (= or +=), dw[o,i] (=), dbias[o] (=) for the layer above; dy is masked by row_code/code and, when
+ * relu_y is given, by relu_y > 0. */
+int missm_small_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw, float* dbias,
+                           int B, int I, int O, const long* row_code, long code, int accumulate_dx, void* stream);
+/* y = x / ||x||_2 * scale   (languagebind/__init__.py:80-83) and its backward. */
+int missm_l2norm_scale_fwd(const float* x, float* y, int B, int D, float scale, void* stream);
+int missm_l2norm_scale_bwd(const float* dy, const float* x, float* dx, int B, int D, float scale, void* stream);
+/* loss = mean_b CE(logits[b], labels[b]) ; dlogits = (softmax - onehot) / B   (nn.CrossEntropyLoss, train_ddp.py:88,250). */
+int missm_cross_entropy(const float* logits, const long* labels, float* loss, float* dlogits, int B, int C, void* stream);
+/* inverted dropout with a counter-based generator: y = x * mask / (1-p); mask saved as bytes (src/model/baseline.py:34). */
+int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream);
+int missm_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, void* stream);
+
+/* Fused Adam over a flat fp32 parameter buffer (torch.optim.Adam semantics, train_ddp.py:205,254):
+ * reads p, g, m, v; writes p, m, v. grad_scale multiplies g first (1/world_size for an all-reduce SUM). */
+int missm_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
+                    float weight_decay, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MISSM_HIP_H */

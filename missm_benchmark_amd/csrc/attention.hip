@@ -1,0 +1,529 @@
+// Fused multi-head attention, forward and backward, for the CLIP towers (head_dim 64 MFMA path; any small L path).
+// Replaces CLIPAttention's unfused bmm + softmax + bmm (third-party, called from
+// languagebind/image/modeling_image.py:121-126,140-145) without ever materialising the S x S scores.
+//
+// Row addressing covers both attention flavours of the video tower without any '(b t) n d <-> (b n) t d' copy
+// (image/modeling_image.py:112-127): token j of sequence q lives at row
+//     (q / seq_div) * seq_outer + (q % seq_div) * seq_inner + j * tok_stride
+// of the fused [rows, 3d] QKV matrix (spatial: div 1, outer S, stride 1; temporal: div S, outer T*S, inner 1, stride S).
+//
+// MFMA kernels (17 <= L <= 256, head_dim 64): one 256-thread workgroup per (sequence, head); the whole K and V
+// of the head sit in LDS (2 x 28 KiB bf16 at L = 197 -> two workgroups per CU).  Scores are computed TRANSPOSED
+// (S^T = K Q^T) so a lane owns one query column: the softmax reduction is register-local plus two xor-shuffles,
+// and the probability tile is already the B operand of the PV product (O^T = V^T P^T) - P never touches LDS.
+// V^T fragments come from ds_read_b64_tr_b16 on the row-major V tile.  The backward runs two passes inside one
+// launch (query-on-lane for dQ, key-on-lane for dK/dV), re-staging LDS in between; D = rowsum(P o dP) is
+// formed in registers, so O is not needed and nothing is accumulated with atomics.
+#include "common.h"
+#include "mma.h"
+#include "missm_internal.h"
+
+namespace missm {
+
+struct AttnArgs {
+  const void* qkv; void* out; float* lse;
+  const void* dout; void* dqkv;
+  int nseq, L, H, d, ld, ldo;
+  int seq_div, seq_outer, seq_inner, tok_stride;
+  int causal; const int* key_mask; float scale;
+};
+
+__device__ __forceinline__ size_t seq_base(const AttnArgs& a, int q) {
+  return (size_t)(q / a.seq_div) * a.seq_outer + (size_t)(q % a.seq_div) * a.seq_inner;
+}
+
+constexpr int HD = 64;
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// stage `rows` (zero-filled up to LP) of one head's [L, 64] slice into a swizzled LDS tile
+template <typename T, int RBv>
+__device__ __forceinline__ void stage_head(char* lds, const T* src, size_t base, int tok_stride, int ld, int col0, int L, int LP,
+                                           int tid) {
+  constexpr int NC = RBv / 16, EPC = 16 / sizeof(T);
+  for (int idx = tid; idx < LP * NC; idx += 256) {
+    const int row = idx / NC, c = idx % NC;
+    u32x4 v = {0, 0, 0, 0};
+    if (row < L) v = *reinterpret_cast<const u32x4*>(src + (base + (size_t)row * tok_stride) * ld + col0 + c * EPC);
+    *reinterpret_cast<u32x4*>(lds + swz<RBv>(row, c * 16)) = v;
+  }
+}
+
+template <typename T, int NTP>
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T);
+  constexpr int LP = NTP * 16;
+  constexpr int KSQ = HD / M_::KS;            // k-steps over head_dim
+  constexpr int NU = NTP / M_::CTILES;        // C-as-operand steps over keys
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + LP * RBv;
+  float* kbias = reinterpret_cast<float*>(smem + 2 * LP * RBv);
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int seq = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const size_t base = seq_base(a, seq);
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const int L = a.L;
+
+  stage_head<T, RBv>(ldsK, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, tid);
+  stage_head<T, RBv>(ldsV, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
+  for (int k = tid; k < LP; k += 256)
+    kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
+  __syncthreads();
+
+  const int nqt = (L + 15) / 16;
+  for (int qt = wave; qt < nqt; qt += 4) {
+    const int qi = qt * 16 + li;
+    const bool qvalid = qi < L;
+    const size_t qrow = base + (size_t)(qvalid ? qi : 0) * a.tok_stride;
+    Frag qf[KSQ];
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qf[ks] = M_::zero();
+      if (qvalid) qf[ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+    }
+    f32x4 p[NTP];
+    float mx = kNegInf;
+#pragma unroll
+    for (int kt = 0; kt < NTP; ++kt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks)
+        acc = M_::step(lds_frag<T>(ldsK, swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T))), qf[ks], acc);
+      const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * lg + r;
+        float s = acc[r] * a.scale + kb[r];
+        if (a.causal && key > qi) s = kNegInf;
+        p[kt][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (mx == kNegInf) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTP; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { p[kt][r] = __expf(p[kt][r] - mx); sum += p[kt][r]; }
+    sum += __shfl_xor(sum, 16, 64);
+    sum += __shfl_xor(sum, 32, 64);
+    const float inv = 1.0f / sum;
+    if (a.lse && qvalid && lg == 0) a.lse[((size_t)seq * a.H + h) * L + qi] = mx + __logf(sum);
+
+    Frag pf[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) pf[u] = M_::from_acc(p[u * M_::CTILES], p[u * M_::CTILES + M_::CTILES - 1]);
+    T* out = static_cast<T*>(a.out);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NU; ++u) acc = M_::step(TrFrag<T, RBv>::load(ldsV, u * M_::KS, dt * 16, lane), pf[u], acc);
+      acc *= inv;
+      if (qvalid) store4(out + qrow * a.ldo + h * HD + dt * 16 + 4 * lg, acc);
+    }
+  }
+}
+
+template <typename T, int NTP>
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T);
+  constexpr int LP = NTP * 16;
+  constexpr int KSQ = HD / M_::KS;
+  constexpr int NU = NTP / M_::CTILES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* X0 = smem;                 // pass A: K   ; pass B: Q
+  char* X1 = smem + LP * RBv;      // pass A: V   ; pass B: dO
+  float* kbias = reinterpret_cast<float*>(smem + 2 * LP * RBv);
+  float* lseL = kbias + LP;
+  float* Dl = lseL + LP;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  const int seq = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const size_t base = seq_base(a, seq);
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const T* dout = static_cast<const T*>(a.dout);
+  T* dqkv = static_cast<T*>(a.dqkv);
+  const int L = a.L;
+  const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
+
+  stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, tid);
+  stage_head<T, RBv>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
+  for (int k = tid; k < LP; k += 256) {
+    kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
+    lseL[k] = k < L ? lse[k] : __builtin_huge_valf();
+    Dl[k] = 0.f;
+  }
+  __syncthreads();
+
+  // ---------------- pass A: query on the lane -> dQ, D ----------------
+  const int nt = (L + 15) / 16;
+  for (int qt = wave; qt < nt; qt += 4) {
+    const int qi = qt * 16 + li;
+    const bool qvalid = qi < L;
+    const size_t qrow = base + (size_t)(qvalid ? qi : 0) * a.tok_stride;
+    Frag qf[KSQ], dof[KSQ];
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qf[ks] = M_::zero(); dof[ks] = M_::zero();
+      if (qvalid) {
+        qf[ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+        dof[ks] = *reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
+      }
+    }
+    const float lq = lseL[qi];
+    f32x4 p_[NTP], ds[NTP];
+    float dsum = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTP; ++kt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        const int off = swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+        s = M_::step(lds_frag<T>(X0, off), qf[ks], s);
+        dp = M_::step(lds_frag<T>(X1, off), dof[ks], dp);
+      }
+      const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + 4 * lg + r;
+        float pv = __expf(s[r] * a.scale + kb[r] - lq);
+        if (a.causal && key > qi) pv = 0.f;
+        dsum += pv * dp[r];
+        p_[kt][r] = pv;
+        ds[kt][r] = dp[r];
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (lg == 0) Dl[qi] = qvalid ? dsum : 0.f;
+#pragma unroll
+    for (int kt = 0; kt < NTP; ++kt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) ds[kt][r] = p_[kt][r] * (ds[kt][r] - dsum) * a.scale;
+    Frag dsf[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) dsf[u] = M_::from_acc(ds[u * M_::CTILES], ds[u * M_::CTILES + M_::CTILES - 1]);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NU; ++u) acc = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf[u], acc);
+      if (qvalid) store4(dqkv + qrow * a.ld + h * HD + dt * 16 + 4 * lg, acc);
+    }
+  }
+  __syncthreads();
+
+  // ---------------- pass B: key on the lane -> dK, dV ----------------
+  stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, tid);
+  stage_head<T, RBv>(X1, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, tid);
+  __syncthreads();
+  for (int kt = wave; kt < nt; kt += 4) {
+    const int key = kt * 16 + li;
+    const bool kin = key < L;
+    const size_t krow = base + (size_t)(kin ? key : 0) * a.tok_stride;
+    Frag kf[KSQ], vf[KSQ];
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      kf[ks] = M_::zero(); vf[ks] = M_::zero();
+      if (kin) {
+        kf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+        vf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+      }
+    }
+    const float kb = kbias[key];
+    f32x4 p_[NTP], ds[NTP];
+#pragma unroll
+    for (int qt = 0; qt < NTP; ++qt) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks) {
+        const int off = swz<RBv>(qt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+        s = M_::step(lds_frag<T>(X0, off), kf[ks], s);
+        dp = M_::step(lds_frag<T>(X1, off), vf[ks], dp);
+      }
+      const f32x4 lq = *reinterpret_cast<const f32x4*>(lseL + qt * 16 + 4 * lg);
+      const f32x4 dq = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int q = qt * 16 + 4 * lg + r;
+        float pv = __expf(s[r] * a.scale + kb - lq[r]);
+        if (a.causal && key > q) pv = 0.f;
+        p_[qt][r] = pv;
+        ds[qt][r] = pv * (dp[r] - dq[r]) * a.scale;
+      }
+    }
+    Frag pf[NU], dsf[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      pf[u] = M_::from_acc(p_[u * M_::CTILES], p_[u * M_::CTILES + M_::CTILES - 1]);
+      dsf[u] = M_::from_acc(ds[u * M_::CTILES], ds[u * M_::CTILES + M_::CTILES - 1]);
+    }
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        dv = M_::step(TrFrag<T, RBv>::load(X1, u * M_::KS, dt * 16, lane), pf[u], dv);
+        dk = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf[u], dk);
+      }
+      if (kin) {
+        store4(dqkv + krow * a.ld + a.d + h * HD + dt * 16 + 4 * lg, dk);
+        store4(dqkv + krow * a.ld + 2 * a.d + h * HD + dt * 16 + 4 * lg, dv);
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Small-sequence path (L <= 32, any head_dim <= 128 that is a multiple of 8): the video tower's temporal
+// attention (L = T = 8, B*197 sequences x 12 heads) and the tiny parity configs.  No MFMA: one wavefront
+// packs 64 / L (sequence, head) pairs, lane = (pair, query); operands sit in LDS as T, math in fp32.
+// HBM-bound by construction (3 KB in, 1 KB out per pair at L = 8).
+// ---------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void stage_small(T* dst, const T* src, const AttnArgs& a, int pair0, int npairs_total, int PW, int hd,
+                                            int ld, int col_base, int lane) {
+  constexpr int EPC = 16 / sizeof(T);
+  const int NC = hd / EPC;
+  const int L = a.L;
+  for (int idx = lane; idx < PW * L * NC; idx += 64) {
+    const int rowid = idx / NC, c = idx % NC;
+    const int pl = rowid / L, j = rowid % L;
+    const int pair = pair0 + pl;
+    u32x4 v = {0, 0, 0, 0};
+    if (pair < npairs_total) {
+      const int seq = pair / a.H, h = pair % a.H;
+      const size_t row = seq_base(a, seq) + (size_t)j * a.tok_stride;
+      v = *reinterpret_cast<const u32x4*>(src + row * ld + col_base + h * hd + c * EPC);
+    }
+    *reinterpret_cast<u32x4*>(dst + (size_t)rowid * hd + c * EPC) = v;
+  }
+}
+
+template <typename T, int MAXL>
+__global__ __launch_bounds__(64) void attn_small_fwd_kernel(AttnArgs a, int hd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = a.L, PW = 64 / L, lane = threadIdx.x;
+  const int total = a.nseq * a.H;
+  const int pair0 = blockIdx.x * PW;
+  T* sQ = reinterpret_cast<T*>(smem);
+  T* sK = sQ + (size_t)PW * L * hd;
+  T* sV = sK + (size_t)PW * L * hd;
+  const T* qkv = static_cast<const T*>(a.qkv);
+  stage_small<T>(sQ, qkv, a, pair0, total, PW, hd, a.ld, 0, lane);
+  stage_small<T>(sK, qkv, a, pair0, total, PW, hd, a.ld, a.d, lane);
+  stage_small<T>(sV, qkv, a, pair0, total, PW, hd, a.ld, 2 * a.d, lane);
+  __syncthreads();
+  const int pl = lane / L, q = lane % L, pair = pair0 + pl;
+  if (pl >= PW || pair >= total) return;
+  const int seq = pair / a.H, h = pair % a.H;
+  const T* Qr = sQ + ((size_t)pl * L + q) * hd;
+  const T* Kp = sK + (size_t)pl * L * hd;
+  const T* Vp = sV + (size_t)pl * L * hd;
+  float s[MAXL];
+  float mx = kNegInf;
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) {
+    s[j] = kNegInf;
+    if (j < L) {
+      float acc = 0.f;
+      for (int d0 = 0; d0 < hd; d0 += 4) {
+        const f32x4 qv = load4(Qr + d0), kv = load4(Kp + (size_t)j * hd + d0);
+        acc += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+      }
+      bool ok = !(a.causal && j > q);
+      if (a.key_mask && a.key_mask[(size_t)seq * L + j] == 0) ok = false;
+      s[j] = ok ? acc * a.scale : kNegInf;
+      mx = fmaxf(mx, s[j]);
+    }
+  }
+  if (mx == kNegInf) mx = 0.f;
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < MAXL; ++j) { s[j] = (j < L) ? __expf(s[j] - mx) : 0.f; sum += s[j]; }
+  const float inv = 1.0f / sum;
+  if (a.lse) a.lse[((size_t)seq * a.H + h) * L + q] = mx + __logf(sum);
+  T* out = static_cast<T*>(a.out) + (seq_base(a, seq) + (size_t)q * a.tok_stride) * a.ldo + h * hd;
+  for (int d0 = 0; d0 < hd; d0 += 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j)
+      if (j < L) { const f32x4 vv = load4(Vp + (size_t)j * hd + d0); acc += vv * s[j]; }
+    acc *= inv;
+    store4(out + d0, acc);
+  }
+}
+
+template <typename T, int MAXL>
+__global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int L = a.L, PW = 64 / L, lane = threadIdx.x;
+  const int total = a.nseq * a.H;
+  const int pair0 = blockIdx.x * PW;
+  const size_t mat = (size_t)PW * L * hd;
+  T* sQ = reinterpret_cast<T*>(smem);
+  T* sK = sQ + mat;
+  T* sV = sK + mat;
+  T* sdO = sV + mat;
+  float* sP = reinterpret_cast<float*>(sdO + mat);   // [PW][L][L]
+  float* sdS = sP + (size_t)PW * L * L;
+  const T* qkv = static_cast<const T*>(a.qkv);
+  stage_small<T>(sQ, qkv, a, pair0, total, PW, hd, a.ld, 0, lane);
+  stage_small<T>(sK, qkv, a, pair0, total, PW, hd, a.ld, a.d, lane);
+  stage_small<T>(sV, qkv, a, pair0, total, PW, hd, a.ld, 2 * a.d, lane);
+  stage_small<T>(sdO, static_cast<const T*>(a.dout), a, pair0, total, PW, hd, a.ldo, 0, lane);
+  __syncthreads();
+  const int pl = lane / L, q = lane % L, pair = pair0 + pl;
+  const bool active = pl < PW && pair < total;
+  const int seq = active ? pair / a.H : 0, h = active ? pair % a.H : 0;
+  const T* Qp = sQ + (size_t)pl * L * hd;
+  const T* Kp = sK + (size_t)pl * L * hd;
+  const T* Vp = sV + (size_t)pl * L * hd;
+  const T* dOp = sdO + (size_t)pl * L * hd;
+  T* dqkv = static_cast<T*>(a.dqkv);
+  if (active) {
+    float p[MAXL], dp[MAXL];
+    float mx = kNegInf;
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) {
+      p[j] = kNegInf; dp[j] = 0.f;
+      if (j < L) {
+        float acc = 0.f, acc2 = 0.f;
+        for (int d0 = 0; d0 < hd; d0 += 4) {
+          const f32x4 qv = load4(Qp + (size_t)q * hd + d0), kv = load4(Kp + (size_t)j * hd + d0);
+          const f32x4 gv = load4(dOp + (size_t)q * hd + d0), vv = load4(Vp + (size_t)j * hd + d0);
+          acc += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
+          acc2 += gv[0] * vv[0] + gv[1] * vv[1] + gv[2] * vv[2] + gv[3] * vv[3];
+        }
+        bool ok = !(a.causal && j > q);
+        if (a.key_mask && a.key_mask[(size_t)seq * L + j] == 0) ok = false;
+        p[j] = ok ? acc * a.scale : kNegInf;
+        dp[j] = acc2;
+        mx = fmaxf(mx, p[j]);
+      }
+    }
+    if (mx == kNegInf) mx = 0.f;
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) { p[j] = (j < L) ? __expf(p[j] - mx) : 0.f; sum += p[j]; }
+    const float inv = 1.0f / sum;
+    float D = 0.f;
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j) { p[j] *= inv; D += p[j] * dp[j]; }
+#pragma unroll
+    for (int j = 0; j < MAXL; ++j)
+      if (j < L) {
+        const float dsv = p[j] * (dp[j] - D) * a.scale;
+        sP[((size_t)pl * L + q) * L + j] = p[j];
+        sdS[((size_t)pl * L + q) * L + j] = dsv;
+        dp[j] = dsv;
+      }
+    T* dq = dqkv + (seq_base(a, seq) + (size_t)q * a.tok_stride) * a.ld + h * hd;
+    for (int d0 = 0; d0 < hd; d0 += 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < MAXL; ++j)
+        if (j < L) { const f32x4 kv = load4(Kp + (size_t)j * hd + d0); acc += kv * dp[j]; }
+      store4(dq + d0, acc);
+    }
+  }
+  __syncthreads();
+  if (active) {  // lane = (pair, key q)
+    T* dk = dqkv + (seq_base(a, seq) + (size_t)q * a.tok_stride) * a.ld + a.d + h * hd;
+    T* dv = dk + a.d;
+    for (int d0 = 0; d0 < hd; d0 += 4) {
+      f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
+      for (int i = 0; i < L; ++i) {
+        const float dsv = sdS[((size_t)pl * L + i) * L + q], pv = sP[((size_t)pl * L + i) * L + q];
+        const f32x4 qv = load4(Qp + (size_t)i * hd + d0), gv = load4(dOp + (size_t)i * hd + d0);
+        ak += qv * dsv;
+        av += gv * pv;
+      }
+      store4(dk + d0, ak);
+      store4(dv + d0, av);
+    }
+  }
+}
+
+}  // namespace missm
+
+using namespace missm;
+
+namespace {
+template <typename K> int launch_dyn(K kernel, dim3 grid, dim3 block, size_t shmem, hipStream_t s, const char* what) {
+  if (shmem > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    if (e != hipSuccess) { missm_set_error("%s: cannot raise dynamic LDS to %zu: %s", what, shmem, hipGetErrorString(e)); return MISSM_ERR_LAUNCH; }
+  }
+  return MISSM_OK;
+}
+
+int fill_args(AttnArgs& a, const void* qkv, void* out, float* lse, const void* dout, void* dqkv, int nseq, int L, int H, int hd,
+              int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal, const int* key_mask,
+              float scale) {
+  a.qkv = qkv; a.out = out; a.lse = lse; a.dout = dout; a.dqkv = dqkv; a.nseq = nseq; a.L = L; a.H = H; a.d = H * hd;
+  a.ld = ld; a.ldo = ldo; a.seq_div = seq_div > 0 ? seq_div : 1; a.seq_outer = seq_outer; a.seq_inner = seq_inner;
+  a.tok_stride = tok_stride; a.causal = causal; a.key_mask = key_mask; a.scale = scale;
+  return MISSM_OK;
+}
+
+template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipStream_t s) {
+  const int L = a.L;
+  if (L <= 32) {
+    const int PW = 64 / L;
+    const int total = a.nseq * a.H;
+    dim3 grid((total + PW - 1) / PW), block(64);
+    size_t shmem = (size_t)PW * L * hd * sizeof(T) * (BWD ? 4 : 3) + (BWD ? (size_t)PW * L * L * 8 : 0);
+#define MISSM_SMALL(MAXL)                                                                                   \
+    do {                                                                                                    \
+      auto k = BWD ? attn_small_bwd_kernel<T, MAXL> : attn_small_fwd_kernel<T, MAXL>;                         \
+      int rc = launch_dyn(k, grid, block, shmem, s, "attn_small"); if (rc) return rc;                        \
+      hipLaunchKernelGGL(k, grid, block, shmem, s, a, hd);                                                   \
+    } while (0)
+    if (L <= 8) MISSM_SMALL(8); else if (L <= 16) MISSM_SMALL(16); else MISSM_SMALL(32);
+#undef MISSM_SMALL
+    return missm_check_launch("attn_small");
+  }
+  if (hd != HD || L > 256) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64 and L<=256)", L, hd); return MISSM_ERR_INVALID; }
+  dim3 grid(a.nseq * a.H), block(256);
+#define MISSM_MFMA(NTP)                                                                                     \
+  do {                                                                                                      \
+    size_t shmem = (size_t)2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1);              \
+    auto k = BWD ? attn_bwd_mfma_kernel<T, NTP> : attn_fwd_mfma_kernel<T, NTP>;                                \
+    int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                            \
+    hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                         \
+  } while (0)
+  if (L <= 96) MISSM_MFMA(6); else if (L <= 224) MISSM_MFMA(14); else MISSM_MFMA(16);
+#undef MISSM_MFMA
+  return missm_check_launch("attn_mfma");
+}
+}  // namespace
+
+extern "C" int missm_attention_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int head_dim, int ld, int ldo,
+                                   int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal, const int* key_mask,
+                                   float scale, int dtype, void* stream) {
+  MISSM_CHECK_ARG(nseq > 0 && L > 0 && H > 0 && head_dim > 0 && head_dim % 8 == 0 && head_dim <= 128, "attention_fwd: bad shape");
+  MISSM_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0, "attention_fwd: ld/ldo must be multiples of 8");
+  AttnArgs a; fill_args(a, qkv, out, lse, nullptr, nullptr, nseq, L, H, head_dim, ld, ldo, seq_div, seq_outer, seq_inner, tok_stride, causal, key_mask, scale);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == kBF16 ? launch_attn<bf16, false>(a, head_dim, s) : launch_attn<float, false>(a, head_dim, s);
+}
+
+extern "C" int missm_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int nseq, int L, int H,
+                                   int head_dim, int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride,
+                                   int causal, const int* key_mask, float scale, int dtype, void* stream) {
+  MISSM_CHECK_ARG(nseq > 0 && L > 0 && H > 0 && head_dim > 0 && head_dim % 8 == 0 && head_dim <= 128, "attention_bwd: bad shape");
+  MISSM_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0, "attention_bwd: ld/ldo must be multiples of 8");
+  AttnArgs a; fill_args(a, qkv, nullptr, const_cast<float*>(lse), dout, dqkv, nseq, L, H, head_dim, ld, ldo, seq_div, seq_outer, seq_inner, tok_stride, causal, key_mask, scale);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  return dtype == kBF16 ? launch_attn<bf16, true>(a, head_dim, s) : launch_attn<float, true>(a, head_dim, s);
+}

@@ -1,0 +1,235 @@
+// LayerNorm forward/backward (eps 1e-5, affine) on the fp32 residual stream, one wavefront per row.
+// Replaces torch's ATen LayerNorm at the reference sites pre_layrnorm / layer_norm1/2 / temporal_layer_norm1 /
+// post_layernorm / final_layer_norm (languagebind/image/modeling_image.py:70,72,82,465,604,606) and the fusion
+// LayerNorm (src/model/baseline.py:48).  HBM-bound: the row lives in registers (one 16-byte load per lane per
+// 256 columns), statistics by xor-shuffles across the 64 lanes, two-pass variance like the reference.
+//
+// Fusions:  * optional per-row additive vector written back to the stream (temporal_embedding add,
+//             image/modeling_image.py:110-114, without materialising the '(b t) n d <-> (b n) t d' shuffles)
+//           * optional row gather on input (CLS / EOT pooling, :658-662, :519-522)
+//           * backward accumulates straight into the fp32 residual-gradient stream and reduces
+//             dgamma/dbeta per workgroup before one 256-byte-contiguous atomic per wave.
+#include "common.h"
+#include "missm_internal.h"
+#include <type_traits>
+
+namespace missm {
+
+struct LnFwdArgs {
+  const float* x;        // [*, cols] fp32 input rows
+  float* x_wb;           // if add != null: x + add is written back here (may alias x)
+  const float* add;      // [mod, cols] or null ; index (row / div) % mod
+  int div, mod;
+  int in_mul;            // input row = row * in_mul + (in_off ? in_off[row] : 0)
+  const int* in_off;
+  const float* gamma; const float* beta;
+  void* y;               // [rows, cols] Tout
+  float* mean; float* rstd;  // [rows] (nullable)
+  int rows, cols; float eps;
+};
+
+template <typename Tout, int CH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
+  const float* xr = a.x + irow * a.cols;
+  f32x4 v[CH];
+  float s = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    if (col < a.cols) {
+      v[c] = load4(xr + col);
+      if (a.add) {
+        f32x4 t = load4(a.add + (size_t)((row / a.div) % a.mod) * a.cols + col);
+        v[c] += t;
+        store4(a.x_wb + irow * a.cols + col, v[c]);
+      }
+      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
+    } else {
+      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  const float mean = wave_sum(s) / a.cols;
+  float q = 0.f;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    if (col < a.cols) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mean; q += d * d; }
+    }
+  }
+  const float rstd = rsqrtf(wave_sum(q) / a.cols + a.eps);
+  if (lane == 0) {
+    if (a.mean) a.mean[row] = mean;
+    if (a.rstd) a.rstd[row] = rstd;
+  }
+  Tout* yr = static_cast<Tout*>(a.y) + (size_t)row * a.cols;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    if (col < a.cols) {
+      const f32x4 gm = load4(a.gamma + col), bt = load4(a.beta + col);
+      f32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * gm[j] + bt[j];
+      store4(yr + col, o);
+    }
+  }
+}
+
+struct LnBwdArgs {
+  const void* dy;        // Tin rows ; dy row = row / dy_div ; scaled by dy_scale
+  int dy_div; float dy_scale;
+  const float* x;        // LN input rows (fp32), gathered like the forward (in_mul / in_off)
+  int in_mul; const int* in_off;
+  const float* mean; const float* rstd; const float* gamma;
+  float* dx;             // fp32, same row mapping as x ; accumulate ? += : =
+  int accumulate;
+  float* dgamma; float* dbeta;  // fp32 [cols], atomically accumulated (caller zeroes)
+  int rows, cols;
+};
+
+template <typename Tin, int CH>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+  __shared__ float red[2][4][CH * 256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  f32x4 ag[CH], ab[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) { ag[c] = f32x4{0.f, 0.f, 0.f, 0.f}; ab[c] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  f32x4 gm[CH];
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int col = (c * 64 + lane) * 4;
+    gm[c] = col < a.cols ? load4(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  const float inv = 1.0f / a.cols;
+  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
+    const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
+    const float* xr = a.x + irow * a.cols;
+    const Tin* dyr = static_cast<const Tin*>(a.dy) + (size_t)(row / a.dy_div) * a.cols;
+    const float mean = a.mean[row], rstd = a.rstd[row];
+    f32x4 xh[CH], g[CH];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < a.cols) {
+        const f32x4 xv = load4(xr + col);
+        f32x4 d = load4(dyr + col);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          d[j] *= a.dy_scale;
+          xh[c][j] = (xv[j] - mean) * rstd;
+          g[c][j] = d[j] * gm[c][j];
+          s1 += g[c][j];
+          s2 += g[c][j] * xh[c][j];
+          ag[c][j] += d[j] * xh[c][j];
+          ab[c][j] += d[j];
+        }
+      } else {
+        xh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+    s1 = wave_sum(s1) * inv;
+    s2 = wave_sum(s2) * inv;
+    float* dxr = a.dx + irow * a.cols;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < a.cols) {
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rstd * (g[c][j] - s1 - xh[c][j] * s2);
+        if (a.accumulate) { const f32x4 p = load4(dxr + col); o += p; }
+        store4(dxr + col, o);
+      }
+    }
+  }
+  // cross-wave reduction of the parameter gradients, then one atomic per column per workgroup
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    store4(&red[0][wave][(c * 64 + lane) * 4], ag[c]);
+    store4(&red[1][wave][(c * 64 + lane) * 4], ab[c]);
+  }
+  __syncthreads();
+  for (int col = threadIdx.x; col < a.cols; col += 256) {
+    const float sg = red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col];
+    const float sb = red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col];
+    if (a.dgamma) atomicAdd(a.dgamma + col, sg);
+    if (a.dbeta) atomicAdd(a.dbeta + col, sb);
+  }
+}
+
+// mean over groups of T consecutive rows: out[b] = mean_t in[b*T + t]  (pooled.reshape(B,T,-1).mean(1), :662)
+__global__ void mean_rows_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int T, int cols) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * cols) return;
+  const int b = idx / cols, c = idx % cols;
+  float s = 0.f;
+  for (int t = 0; t < T; ++t) s += in[((size_t)b * T + t) * cols + c];
+  out[idx] = s / T;
+}
+
+template <typename Tout, typename Fn> static int dispatch_ch(int cols, Fn&& fn) {
+  if (cols <= 256) return fn(std::integral_constant<int, 1>{});
+  if (cols <= 512) return fn(std::integral_constant<int, 2>{});
+  if (cols <= 768) return fn(std::integral_constant<int, 3>{});
+  if (cols <= 1024) return fn(std::integral_constant<int, 4>{});
+  if (cols <= 2048) return fn(std::integral_constant<int, 8>{});
+  missm_set_error("layernorm: cols %d > 2048 unsupported", cols);
+  return MISSM_ERR_INVALID;
+}
+
+}  // namespace missm
+
+using namespace missm;
+
+extern "C" int missm_layernorm_fwd(const float* x, float* x_wb, const float* add, int add_div, int add_mod, int in_mul,
+                                   const int* in_off, const float* gamma, const float* beta, void* y, float* mean, float* rstd,
+                                   int rows, int cols, float eps, int out_dtype, void* stream) {
+  MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_fwd: cols must be a positive multiple of 4");
+  MISSM_CHECK_ARG(!add || (x_wb && add_div > 0 && add_mod > 0), "layernorm_fwd: add needs x_wb, div, mod");
+  LnFwdArgs a{x, x_wb, add, add_div > 0 ? add_div : 1, add_mod > 0 ? add_mod : 1, in_mul > 0 ? in_mul : 1, in_off, gamma, beta,
+              y, mean, rstd, rows, cols, eps};
+  dim3 grid((rows + 3) / 4), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = dispatch_ch<void>(cols, [&](auto ch) {
+    constexpr int CH = decltype(ch)::value;
+    if (out_dtype == kBF16) hipLaunchKernelGGL((ln_fwd_kernel<bf16, CH>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((ln_fwd_kernel<float, CH>), grid, block, 0, s, a);
+    return MISSM_OK;
+  });
+  if (rc != MISSM_OK) return rc;
+  return missm_check_launch("layernorm_fwd");
+}
+
+extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
+                                   const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate,
+                                   float* dgamma, float* dbeta, int rows, int cols, int dy_dtype, void* stream) {
+  MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd: cols must be a positive multiple of 4");
+  LnBwdArgs a{dy, dy_div > 0 ? dy_div : 1, dy_scale, x, in_mul > 0 ? in_mul : 1, in_off, mean, rstd, gamma, dx, accumulate,
+              dgamma, dbeta, rows, cols};
+  int blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  dim3 grid(blocks), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = dispatch_ch<void>(cols, [&](auto ch) {
+    constexpr int CH = decltype(ch)::value;
+    if (dy_dtype == kBF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16, CH>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((ln_bwd_kernel<float, CH>), grid, block, 0, s, a);
+    return MISSM_OK;
+  });
+  if (rc != MISSM_OK) return rc;
+  return missm_check_launch("layernorm_bwd");
+}
+
+extern "C" int missm_mean_rows(const float* in, float* out, int B, int T, int cols, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && T > 0 && cols > 0, "mean_rows: bad shape");
+  const int n = B * cols;
+  hipLaunchKernelGGL(mean_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), in, out, B, T, cols);
+  return missm_check_launch("mean_rows");
+}

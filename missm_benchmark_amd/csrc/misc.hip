@@ -1,0 +1,342 @@
+// Embedding, pooling-tail, fusion-projection, loss and optimizer kernels (HBM- or launch-bound, all fp32 math).
+#include "common.h"
+#include "missm_internal.h"
+
+namespace missm {
+
+// ---- patch unfold: the k = stride = ps conv (video/modeling_video.py:29-35) becomes a GEMM over these rows ----
+template <typename T>
+__global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ px, T* __restrict__ out, int B, int Tn, int C, int H,
+                                                    int W, int ps, long sb, long st, long sc) {
+  const int gw = W / ps, gh = H / ps, P = gw * gh, K = C * ps * ps;
+  const int quads = K / 4;                       // ps % 4 == 0: 4 consecutive kx share a pixel row
+  const long total = (long)B * Tn * P * quads;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int qd = idx % quads;
+    const long rowi = idx / quads;
+    const int p = rowi % P;
+    const long n = rowi / P;
+    const int b = n / Tn, t = n % Tn;
+    const int k = qd * 4, c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
+    const int py = p / gw, pxx = p % gw;
+    const float* src = px + b * sb + t * st + c * sc + (long)(py * ps + ky) * W + pxx * ps + kx;
+    store4(out + rowi * K + k, load4(src));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_assemble_kernel(const T* __restrict__ patches, const float* __restrict__ cls,
+                                                            const float* __restrict__ pos, float* __restrict__ x, int N, int S, int d) {
+  const int q4 = d / 4;
+  const long total = (long)N * S * q4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (idx % q4) * 4;
+    const long row = idx / q4;
+    const int s = row % S;
+    const long n = row / S;
+    f32x4 v = (s == 0) ? load4(cls + c) : load4(patches + (n * (S - 1) + s - 1) * d + c);
+    v += load4(pos + (long)s * d + c);
+    store4(x + row * d + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void token_embed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ tok,
+                                                             const float* __restrict__ pos, float* __restrict__ h, int B, int S, int d) {
+  const int q4 = d / 4;
+  const long total = (long)B * S * q4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (idx % q4) * 4;
+    const long row = idx / q4;
+    const int s = row % S;
+    f32x4 v = load4(tok + ids[row] * d + c);
+    v += load4(pos + (long)s * d + c);
+    store4(h + row * d + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void token_embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dh,
+                                                             float* __restrict__ dtok, float* __restrict__ dpos, int B, int S, int d) {
+  const long total = (long)B * S * d;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = idx % d;
+    const long row = idx / d;
+    const int s = row % S;
+    const float g = dh[idx];
+    atomicAdd(dtok + ids[row] * d + c, g);
+    atomicAdd(dpos + (long)s * d + c, g);
+  }
+}
+
+__global__ void argmax_rows_kernel(const long* __restrict__ ids, int* __restrict__ out, int B, int S) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  long best = ids[(long)b * S]; int bi = 0;
+  for (int s = 1; s < S; ++s) { const long v = ids[(long)b * S + s]; if (v > best) { best = v; bi = s; } }
+  out[b] = bi;
+}
+
+// ---- small fp32 linears of the projection / fusion tail: one wavefront per output element ----
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ y, int B, int I, int O,
+                                                              int relu, const long* __restrict__ row_code, long code, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= (long)B * O) return;
+  const int b = e / O, o = e % O;
+  float acc = 0.f;
+  const bool masked = row_code && row_code[b] == code;
+  if (!masked) {
+    const float* xr = x + (long)b * I;
+    const float* wr = w + (long)o * I;
+    for (int i = lane * 4; i < I; i += 256) {
+      const f32x4 a = load4(xr + i), c = load4(wr + i);
+      acc += a[0] * c[0] + a[1] * c[1] + a[2] * c[2] + a[3] * c[3];
+    }
+    acc = wave_sum(acc);
+    if (bias) acc += bias[o];
+    if (relu) acc = fmaxf(acc, 0.f);
+  }
+  if (lane == 0) y[e] = accumulate ? y[e] + acc : acc;
+}
+
+// effective dy (masked by row code and by relu) helper
+__device__ __forceinline__ float eff_dy(const float* dy, const float* relu_y, const long* row_code, long code, int b, int o, int O) {
+  if (row_code && row_code[b] == code) return 0.f;
+  const float g = dy[(long)b * O + o];
+  if (relu_y && relu_y[(long)b * O + o] <= 0.f) return 0.f;
+  return g;
+}
+
+// dx[b, i] = sum_o dyeff[b, o] w[o, i]
+__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                             const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
+                                                             const long* __restrict__ row_code, long code, int accumulate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * I) return;
+  const int b = idx / I, i = idx % I;
+  float acc = 0.f;
+  for (int o = 0; o < O; ++o) acc += eff_dy(dy, relu_y, row_code, code, b, o, O) * w[(long)o * I + i];
+  dx[idx] = accumulate ? dx[idx] + acc : acc;
+}
+
+// dw[o, i] = sum_b dyeff[b, o] x[b, i] ; dbias[o] = sum_b dyeff[b, o]
+__global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                             const float* __restrict__ relu_y, float* __restrict__ dw,
+                                                             float* __restrict__ dbias, int B, int I, int O,
+                                                             const long* __restrict__ row_code, long code) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)O * I) return;
+  const int o = idx / I, i = idx % I;
+  float acc = 0.f, accb = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float g = eff_dy(dy, relu_y, row_code, code, b, o, O);
+    acc += g * x[(long)b * I + i];
+    accb += g;
+  }
+  dw[idx] = acc;
+  if (dbias && i == 0) dbias[o] = accb;
+}
+
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float ss = 0.f;
+  for (int i = lane; i < D; i += 64) { const float v = x[(long)b * D + i]; ss += v * v; }
+  const float inv = scale / sqrtf(wave_sum(ss));
+  for (int i = lane; i < D; i += 64) y[(long)b * D + i] = x[(long)b * D + i] * inv;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, float* __restrict__ dx,
+                                                        int B, int D, float scale) {
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= B) return;
+  float ss = 0.f, dot = 0.f;
+  for (int i = lane; i < D; i += 64) { const float v = x[(long)b * D + i]; ss += v * v; dot += v * dy[(long)b * D + i]; }
+  ss = wave_sum(ss); dot = wave_sum(dot);
+  const float rn = 1.0f / sqrtf(ss);
+  for (int i = lane; i < D; i += 64) {
+    const float v = x[(long)b * D + i];
+    dx[(long)b * D + i] = scale * rn * (dy[(long)b * D + i] - v * dot / ss);
+  }
+}
+
+__global__ __launch_bounds__(64) void cross_entropy_kernel(const float* __restrict__ logits, const long* __restrict__ labels,
+                                                          float* __restrict__ loss, float* __restrict__ dlogits, int B, int C) {
+  // single wavefront: lane strides over samples, then one shuffle reduction (B, C are small)
+  const int lane = threadIdx.x;
+  float part = 0.f;
+  for (int b = lane; b < B; b += 64) {
+    const float* lr = logits + (long)b * C;
+    float mx = lr[0];
+    for (int c = 1; c < C; ++c) mx = fmaxf(mx, lr[c]);
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) s += expf(lr[c] - mx);
+    const float lse = mx + logf(s);
+    const long y = labels[b];
+    part += lse - lr[y];
+    if (dlogits)
+      for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = (expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) / B;
+  }
+  part = wave_sum(part);
+  if (lane == 0) *loss = part / B;
+}
+
+__device__ __forceinline__ uint32_t hash_u64(unsigned long long x) {  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  return (uint32_t)((x ^ (x >> 31)) >> 32);
+}
+
+__global__ __launch_bounds__(256) void dropout_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, unsigned char* __restrict__ mask,
+                                                         long n, float p, unsigned long long seed) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float u = hash_u64(seed * 0x100000001B3ull + (unsigned long long)i) * (1.0f / 4294967296.0f);
+  const unsigned char keep = u >= p;
+  mask[i] = keep;
+  y[i] = keep ? x[i] / (1.0f - p) : 0.f;
+}
+
+__global__ __launch_bounds__(256) void dropout_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ mask,
+                                                         float* __restrict__ dx, long n, float p) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  dx[i] = mask[i] ? dy[i] / (1.0f - p) : 0.f;
+}
+
+// Fused Adam: 16 B read of p, g, m, v + 12 B write of p, m, v per parameter = 28 B/param of HBM traffic.
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                  float* __restrict__ v, long n4, long n, float lr_bc1, float inv_sqrt_bc2, float beta1,
+                                                  float beta2, float eps, float wd, float gscale) {
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    const long i = q * 4;
+    if (i + 3 < n) {
+      f32x4 pv = load4(p + i), gv = load4(g + i), mv = load4(m + i), vv = load4(v + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float gg = gv[j] * gscale + wd * pv[j];
+        mv[j] = beta1 * mv[j] + (1.f - beta1) * gg;
+        vv[j] = beta2 * vv[j] + (1.f - beta2) * gg * gg;
+        pv[j] -= lr_bc1 * mv[j] / (sqrtf(vv[j]) * inv_sqrt_bc2 + eps);
+      }
+      store4(p + i, pv); store4(m + i, mv); store4(v + i, vv);
+    } else {
+      for (long k = i; k < n; ++k) {
+        float gg = g[k] * gscale + wd * p[k];
+        m[k] = beta1 * m[k] + (1.f - beta1) * gg;
+        v[k] = beta2 * v[k] + (1.f - beta2) * gg * gg;
+        p[k] -= lr_bc1 * m[k] / (sqrtf(v[k]) * inv_sqrt_bc2 + eps);
+      }
+    }
+  }
+}
+
+static inline int grid_for(long total, int cap = 4096) {
+  long g = (total + 255) / 256;
+  if (g > cap) g = cap;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+}  // namespace missm
+
+using namespace missm;
+#define S_(x) static_cast<hipStream_t>(x)
+
+extern "C" int missm_unfold_patches(const float* pixels, void* out, int B, int T, int C, int H, int W, int ps, long stride_b,
+                                    long stride_t, long stride_c, int dtype, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && T > 0 && C > 0 && ps > 0 && ps % 4 == 0 && H % ps == 0 && W % ps == 0, "unfold: bad shape (patch size must be a multiple of 4)");
+  MISSM_CHECK_ARG(W % 4 == 0 && stride_b % 4 == 0 && stride_t % 4 == 0 && stride_c % 4 == 0, "unfold: strides must keep 16-byte alignment");
+  const long total = (long)B * T * (H / ps) * (W / ps) * (C * ps * ps / 4);
+  dim3 grid(grid_for(total, 8192)), block(256);
+  if (dtype == kBF16) hipLaunchKernelGGL(unfold_kernel<bf16>, grid, block, 0, S_(stream), pixels, (bf16*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c);
+  else hipLaunchKernelGGL(unfold_kernel<float>, grid, block, 0, S_(stream), pixels, (float*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c);
+  return missm_check_launch("unfold_patches");
+}
+
+extern "C" int missm_embed_assemble(const void* patches, const float* cls, const float* pos, float* x, int N, int S, int d, int dtype,
+                                    void* stream) {
+  MISSM_CHECK_ARG(N > 0 && S > 1 && d > 0 && d % 4 == 0, "embed_assemble: bad shape");
+  dim3 grid(grid_for((long)N * S * (d / 4), 8192)), block(256);
+  if (dtype == kBF16) hipLaunchKernelGGL(embed_assemble_kernel<bf16>, grid, block, 0, S_(stream), (const bf16*)patches, cls, pos, x, N, S, d);
+  else hipLaunchKernelGGL(embed_assemble_kernel<float>, grid, block, 0, S_(stream), (const float*)patches, cls, pos, x, N, S, d);
+  return missm_check_launch("embed_assemble");
+}
+
+extern "C" int missm_token_embed_fwd(const long* ids, const float* tok, const float* pos, float* h, int B, int S, int d, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && S > 0 && d > 0 && d % 4 == 0, "token_embed_fwd: bad shape");
+  hipLaunchKernelGGL(token_embed_fwd_kernel, dim3(grid_for((long)B * S * (d / 4))), dim3(256), 0, S_(stream), ids, tok, pos, h, B, S, d);
+  return missm_check_launch("token_embed_fwd");
+}
+
+extern "C" int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* dpos, int B, int S, int d, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && S > 0 && d > 0, "token_embed_bwd: bad shape");
+  hipLaunchKernelGGL(token_embed_bwd_kernel, dim3(grid_for((long)B * S * d)), dim3(256), 0, S_(stream), ids, dh, dtok, dpos, B, S, d);
+  return missm_check_launch("token_embed_bwd");
+}
+
+extern "C" int missm_argmax_rows(const long* ids, int* out, int B, int S, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && S > 0, "argmax_rows: bad shape");
+  hipLaunchKernelGGL(argmax_rows_kernel, dim3((B + 63) / 64), dim3(64), 0, S_(stream), ids, out, B, S);
+  return missm_check_launch("argmax_rows");
+}
+
+extern "C" int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
+                                      const long* row_code, long code, int accumulate, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && I % 4 == 0, "small_linear_fwd: bad shape (I must be a multiple of 4)");
+  const long e = (long)B * O;
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, relu, row_code, code, accumulate);
+  return missm_check_launch("small_linear_fwd");
+}
+
+extern "C" int missm_small_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
+                                      float* dbias, int B, int I, int O, const long* row_code, long code, int accumulate_dx,
+                                      void* stream) {
+  MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0, "small_linear_bwd: bad shape");
+  if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, row_code, code, accumulate_dx);
+  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, row_code, code);
+  return missm_check_launch("small_linear_bwd");
+}
+
+extern "C" int missm_l2norm_scale_fwd(const float* x, float* y, int B, int D, float scale, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && D > 0, "l2norm_fwd: bad shape");
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((B + 3) / 4), dim3(256), 0, S_(stream), x, y, B, D, scale);
+  return missm_check_launch("l2norm_fwd");
+}
+
+extern "C" int missm_l2norm_scale_bwd(const float* dy, const float* x, float* dx, int B, int D, float scale, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && D > 0, "l2norm_bwd: bad shape");
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((B + 3) / 4), dim3(256), 0, S_(stream), dy, x, dx, B, D, scale);
+  return missm_check_launch("l2norm_bwd");
+}
+
+extern "C" int missm_cross_entropy(const float* logits, const long* labels, float* loss, float* dlogits, int B, int C, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && C > 0, "cross_entropy: bad shape");
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(64), 0, S_(stream), logits, labels, loss, dlogits, B, C);
+  return missm_check_launch("cross_entropy");
+}
+
+extern "C" int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream) {
+  MISSM_CHECK_ARG(n > 0 && p >= 0.f && p < 1.f, "dropout_fwd: bad args");
+  hipLaunchKernelGGL(dropout_fwd_kernel, dim3((n + 255) / 256), dim3(256), 0, S_(stream), x, y, mask, n, p, seed);
+  return missm_check_launch("dropout_fwd");
+}
+
+extern "C" int missm_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, void* stream) {
+  MISSM_CHECK_ARG(n > 0 && p >= 0.f && p < 1.f, "dropout_bwd: bad args");
+  hipLaunchKernelGGL(dropout_bwd_kernel, dim3((n + 255) / 256), dim3(256), 0, S_(stream), dy, mask, dx, n, p);
+  return missm_check_launch("dropout_bwd");
+}
+
+extern "C" int missm_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, float grad_scale, void* stream) {
+  MISSM_CHECK_ARG(n > 0 && step >= 1, "adam_step: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  const long n4 = (n + 3) / 4;
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n4, 2048)), dim3(256), 0, S_(stream), p, g, m, v, n4, n, (float)(lr / bc1),
+                     (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale);
+  return missm_check_launch("adam_step");
+}

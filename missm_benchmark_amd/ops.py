@@ -1,0 +1,223 @@
+"""Tensor-level wrappers over the C ABI: torch tensors in, device pointers + current HIP stream out.
+
+PyTorch is plumbing here (device memory, streams); all arithmetic happens in ``libmissm_hip.so``.
+Every wrapper validates shapes on the host before the launch so a kernel never sees a bad extent.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+F32, BF16 = 0, 1
+ACT_NONE, ACT_QGELU, ACT_GELU, ACT_DQGELU, ACT_DGELU, ACT_RELU = 0, 1, 2, 3, 4, 5
+ACT_CODE = {"quick_gelu": ACT_QGELU, "gelu": ACT_GELU}
+ACT_GRAD = {ACT_QGELU: ACT_DQGELU, ACT_GELU: ACT_DGELU}
+
+
+def dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return F32
+    if t.dtype == torch.bfloat16:
+        return BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def torch_dtype(code: int) -> torch.dtype:
+    return torch.float32 if code == F32 else torch.bfloat16
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _req(t: torch.Tensor, name: str):
+    if not t.is_cuda:
+        raise _lib.MissmError(f"{name}: tensor must live on the GPU (no CPU fallback exists)")
+    if not t.is_contiguous() and t.dim() > 0 and t.stride(-1) != 1:
+        raise _lib.MissmError(f"{name}: innermost dimension must be contiguous")
+
+
+def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, bias=None, resid=None, aux_in=None, aux_out=None,
+            act: int = ACT_NONE, alpha: float = 1.0, accumulate: bool = False, M=None, N=None, K=None):
+    """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+bias) -> act (+resid). a/b share a dtype; out is that dtype or fp32."""
+    _req(a, "gemm a"); _req(b, "gemm b"); _req(out, "gemm out")
+    M = a.shape[0] if M is None else M
+    N = b.shape[0] if N is None else N
+    K = a.shape[1] if K is None else K
+    if a.dtype != b.dtype:
+        raise _lib.MissmError("gemm: operand dtypes differ")
+    if K > a.shape[1] or K > b.shape[1] or M > a.shape[0] or N > b.shape[0] or out.shape[0] < M or out.shape[1] < N:
+        raise _lib.MissmError(f"gemm: shapes a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)} vs M{M} N{N} K{K}")
+    out_f32 = int(out.dtype == torch.float32)
+    if not out_f32 and (out.dtype != a.dtype or resid is not None or accumulate):
+        raise _lib.MissmError("gemm: output must be fp32 (required for resid/accumulate) or the operand dtype")
+    aux = aux_in if aux_in is not None else aux_out
+    ldaux = aux.stride(0) if aux is not None else out.stride(0)
+    if aux is not None and aux.dtype != a.dtype:
+        raise _lib.MissmError("gemm: aux dtype must match the operands")
+    if resid is not None and (resid.dtype != torch.float32 or resid.stride(0) != out.stride(0)):
+        raise _lib.MissmError("gemm: resid must be fp32 with the output's leading dimension")
+    _lib.call("missm_gemm_nt", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+              float(alpha), _p(bias), _p(resid), _p(aux_in), _p(aux_out), ldaux, act, out_f32, int(accumulate), dt(a), _s())
+    return out
+
+
+def transpose_pad(x: torch.Tensor, out: torch.Tensor, colsum: Optional[torch.Tensor] = None, R=None, C=None):
+    """out[C, ldo] = x[R, C]^T, zero padded on the right up to out.stride(0)."""
+    R = x.shape[0] if R is None else R
+    C = x.shape[1] if C is None else C
+    if out.shape[0] < C or out.stride(0) < R or out.dtype != x.dtype:
+        raise _lib.MissmError("transpose_pad: bad output")
+    _lib.call("missm_transpose_pad", x.data_ptr(), out.data_ptr(), R, C, x.stride(0), out.stride(0), _p(colsum), dt(x), _s())
+    return out
+
+
+def colsum(x: torch.Tensor, out: torch.Tensor, div: int = 1, mod: int = 1, R=None):
+    R = x.shape[0] if R is None else R
+    Cn = x.shape[1]
+    if out.numel() < mod * Cn or out.dtype != torch.float32:
+        raise _lib.MissmError("colsum: bad output")
+    _lib.call("missm_colsum", x.data_ptr(), out.data_ptr(), R, Cn, x.stride(0), div, mod, dt(x), _s())
+    return out
+
+
+def cast_weight(src: torch.Tensor, dst: Optional[torch.Tensor], dst_t: Optional[torch.Tensor]):
+    R, Cn = src.shape
+    ref = dst if dst is not None else dst_t
+    _lib.call("missm_cast_weight", src.data_ptr(), _p(dst), _p(dst_t), R, Cn, dt(ref), _s())
+
+
+def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, *, add=None, add_div=1, add_mod=1, in_mul=1, in_off=None):
+    _lib.call("missm_layernorm_fwd", x.data_ptr(), x.data_ptr() if add is not None else None, _p(add), add_div, add_mod, in_mul,
+              _p(in_off), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _p(mean), _p(rstd), rows, cols, float(eps), dt(y), _s())
+    return y
+
+
+def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, cols, *, accumulate=True, dy_div=1, dy_scale=1.0,
+                  in_mul=1, in_off=None):
+    _lib.call("missm_layernorm_bwd", dy.data_ptr(), dy_div, float(dy_scale), x.data_ptr(), in_mul, _p(in_off), mean.data_ptr(),
+              rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), int(accumulate), _p(dgamma), _p(dbeta), rows, cols, dt(dy), _s())
+    return dx
+
+
+def mean_rows(x, out, B, T, cols):
+    _lib.call("missm_mean_rows", x.data_ptr(), out.data_ptr(), B, T, cols, _s())
+    return out
+
+
+def attention_fwd(qkv, out, lse, nseq, L, H, hd, *, seq_div=1, seq_outer=None, seq_inner=0, tok_stride=1, causal=False,
+                  key_mask=None, scale=None):
+    seq_outer = L if seq_outer is None else seq_outer
+    scale = hd ** -0.5 if scale is None else scale
+    rows_needed = ((nseq - 1) // seq_div) * seq_outer + ((nseq - 1) % seq_div) * seq_inner + (L - 1) * tok_stride + 1
+    if qkv.shape[0] < rows_needed or out.shape[0] < rows_needed or qkv.shape[1] < 3 * H * hd or out.shape[1] < H * hd:
+        raise _lib.MissmError("attention_fwd: row addressing exceeds the buffers")
+    if key_mask is not None and (key_mask.dtype != torch.int32 or key_mask.numel() < nseq * L):
+        raise _lib.MissmError("attention_fwd: key_mask must be int32 [nseq, L]")
+    if lse is not None and lse.numel() < nseq * H * L:
+        raise _lib.MissmError("attention_fwd: lse too small")
+    _lib.call("missm_attention_fwd", qkv.data_ptr(), out.data_ptr(), _p(lse), nseq, L, H, hd, qkv.stride(0), out.stride(0),
+              seq_div, seq_outer, seq_inner, tok_stride, int(causal), _p(key_mask), float(scale), dt(qkv), _s())
+    return out
+
+
+def attention_bwd(qkv, dout, lse, dqkv, nseq, L, H, hd, *, seq_div=1, seq_outer=None, seq_inner=0, tok_stride=1, causal=False,
+                  key_mask=None, scale=None):
+    seq_outer = L if seq_outer is None else seq_outer
+    scale = hd ** -0.5 if scale is None else scale
+    rows_needed = ((nseq - 1) // seq_div) * seq_outer + ((nseq - 1) % seq_div) * seq_inner + (L - 1) * tok_stride + 1
+    if min(qkv.shape[0], dout.shape[0], dqkv.shape[0]) < rows_needed or dqkv.stride(0) != qkv.stride(0):
+        raise _lib.MissmError("attention_bwd: row addressing exceeds the buffers")
+    _lib.call("missm_attention_bwd", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), nseq, L, H, hd,
+              qkv.stride(0), dout.stride(0), seq_div, seq_outer, seq_inner, tok_stride, int(causal), _p(key_mask), float(scale),
+              dt(qkv), _s())
+    return dqkv
+
+
+def unfold_patches(pixels: torch.Tensor, out: torch.Tensor, ps: int):
+    """pixels fp32 [N,C,H,W] or [B,C,T,H,W] -> out[(n p), C*ps*ps]."""
+    if pixels.dim() == 4:
+        B, Cc, H, W = pixels.shape
+        T, sb, st, sc = 1, pixels.stride(0), 0, pixels.stride(1)
+    else:
+        B, Cc, T, H, W = pixels.shape
+        sb, sc, st = pixels.stride(0), pixels.stride(1), pixels.stride(2)
+    if pixels.stride(-1) != 1 or pixels.stride(-2) != W or pixels.dtype != torch.float32:
+        raise _lib.MissmError("unfold_patches: need fp32 pixels with contiguous HxW planes")
+    P = (H // ps) * (W // ps)
+    if out.shape[0] < B * T * P or out.shape[1] != Cc * ps * ps:
+        raise _lib.MissmError("unfold_patches: bad output")
+    _lib.call("missm_unfold_patches", pixels.data_ptr(), out.data_ptr(), B, T, Cc, H, W, ps, sb, st, sc, dt(out), _s())
+    return out
+
+
+def embed_assemble(patches, cls, pos, x, N, S, d):
+    _lib.call("missm_embed_assemble", patches.data_ptr(), cls.data_ptr(), pos.data_ptr(), x.data_ptr(), N, S, d, dt(patches), _s())
+    return x
+
+
+def token_embed_fwd(ids, tok, pos, h, B, S, d):
+    _lib.call("missm_token_embed_fwd", ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), h.data_ptr(), B, S, d, _s())
+    return h
+
+
+def token_embed_bwd(ids, dh, dtok, dpos, B, S, d):
+    _lib.call("missm_token_embed_bwd", ids.data_ptr(), dh.data_ptr(), dtok.data_ptr(), dpos.data_ptr(), B, S, d, _s())
+
+
+def argmax_rows(ids, out, B, S):
+    _lib.call("missm_argmax_rows", ids.data_ptr(), out.data_ptr(), B, S, _s())
+    return out
+
+
+def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, accumulate=False):
+    B, I = x.shape
+    O = w.shape[0]
+    _lib.call("missm_small_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, I, O, int(relu), _p(row_code),
+              int(code), int(accumulate), _s())
+    return y
+
+
+def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, accumulate_dx=False):
+    B, I = x.shape
+    O = w.shape[0]
+    _lib.call("missm_small_linear_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(relu_y), _p(dx), _p(dw), _p(dbias), B, I, O,
+              _p(row_code), int(code), int(accumulate_dx), _s())
+
+
+def l2norm_scale_fwd(x, y, scale):
+    _lib.call("missm_l2norm_scale_fwd", x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], float(scale), _s())
+    return y
+
+
+def l2norm_scale_bwd(dy, x, dx, scale):
+    _lib.call("missm_l2norm_scale_bwd", dy.data_ptr(), x.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1], float(scale), _s())
+    return dx
+
+
+def cross_entropy(logits, labels, loss, dlogits):
+    _lib.call("missm_cross_entropy", logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dlogits), logits.shape[0],
+              logits.shape[1], _s())
+    return loss
+
+
+def dropout_fwd(x, y, mask, p, seed):
+    _lib.call("missm_dropout_fwd", x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), int(seed), _s())
+    return y
+
+
+def dropout_bwd(dy, mask, dx, p):
+    _lib.call("missm_dropout_bwd", dy.data_ptr(), mask.data_ptr(), dx.data_ptr(), dy.numel(), float(p), _s())
+    return dx
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
+    _lib.call("missm_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(step), float(lr),
+              float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _s())

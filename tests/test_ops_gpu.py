@@ -1,0 +1,369 @@
+"""Op-level parity of every HIP kernel (through the C ABI) against plain fp32 torch on the CPU.
+
+Tolerances: fp32 instantiation 2e-5 relative to the output scale (exact-f32 MFMA, different summation order);
+bf16 instantiation 2e-2 (8-bit mantissa operands, fp32 accumulation)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from missm_benchmark_amd import ops as _ops
+    return _ops
+
+
+def dev(t, dtype=None):
+    t = t.cuda()
+    return t.to(dtype) if dtype is not None else t
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all(), "non-finite output"
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def q(t, dtype):
+    """round-trip through the device dtype so the reference sees the same operand values"""
+    return t.to(dtype).float()
+
+
+# ------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 5, 256), (64, 2304, 64)])
+def test_gemm_bias(ops, dtype, M, N, K):
+    a, b, bias = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2), dtype), rnd(N, seed=3)
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm_nt(dev(a, dtype), dev(b, dtype), out, bias=dev(bias), alpha=0.5)
+    ref = 0.5 * a @ b.t() + bias
+    assert rel(out, ref) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_epilogues(ops, dtype):
+    M, N, K = 200, 256, 128
+    a, b, bias = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2, scale=0.1), dtype), rnd(N, seed=3)
+    A, Bm = dev(a, dtype), dev(b, dtype)
+    pre = a @ b.t() + bias
+    # quick_gelu with saved pre-activation
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    aux = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm_nt(A, Bm, out, bias=dev(bias), act=ops.ACT_QGELU, aux_out=aux)
+    assert rel(aux, pre) < TOL[dtype]
+    assert rel(out, pre * torch.sigmoid(1.702 * pre)) < TOL[dtype]
+    # erf gelu
+    ops.gemm_nt(A, Bm, out, bias=dev(bias), act=ops.ACT_GELU)
+    assert rel(out, F.gelu(pre)) < TOL[dtype]
+    # derivative epilogues
+    u = q(rnd(M, N, seed=5), dtype)
+    ur = u.clone().requires_grad_(True)
+    (ur * torch.sigmoid(1.702 * ur)).sum().backward()
+    ops.gemm_nt(A, Bm, out, act=ops.ACT_DQGELU, aux_in=dev(u, dtype))
+    assert rel(out, (a @ b.t()) * ur.grad) < TOL[dtype]
+    ur.grad = None
+    F.gelu(ur).sum().backward()
+    ops.gemm_nt(A, Bm, out, act=ops.ACT_DGELU, aux_in=dev(u, dtype))
+    assert rel(out, (a @ b.t()) * ur.grad) < TOL[dtype]
+    # fp32 output with residual (in place) and accumulate
+    res = rnd(M, N, seed=6)
+    o32 = dev(res.clone())
+    ops.gemm_nt(A, Bm, o32, bias=dev(bias), resid=o32)
+    assert rel(o32, res + pre) < TOL[dtype]
+    acc = dev(res.clone())
+    ops.gemm_nt(A, Bm, acc, accumulate=True)
+    assert rel(acc, res + a @ b.t()) < TOL[dtype]
+    # relu
+    o32 = torch.empty(M, N, device="cuda")
+    ops.gemm_nt(A, Bm, o32, bias=dev(bias), act=ops.ACT_RELU)
+    assert rel(o32, pre.relu()) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_zero_padded_k(ops, dtype):
+    """weight-gradient form: both operands are transposed copies zero-padded along K"""
+    R, Ca, Cb = 197 * 3, 96, 160
+    x, dy = q(rnd(R, Ca, seed=1), dtype), q(rnd(R, Cb, seed=2), dtype)
+    Rp = (R + 63) // 64 * 64
+    xt = torch.empty(Ca, Rp, device="cuda", dtype=dtype)
+    dyt = torch.empty(Cb, Rp, device="cuda", dtype=dtype)
+    cs = torch.zeros(Cb, device="cuda")
+    ops.transpose_pad(dev(x, dtype), xt)
+    ops.transpose_pad(dev(dy, dtype), dyt, colsum=cs)
+    assert rel(xt[:, :R], x.t()) == 0 and float(xt[:, R:].float().abs().max()) == 0
+    assert rel(cs, dy.sum(0)) < 1e-5
+    dw = torch.empty(Cb, Ca, device="cuda")
+    ops.gemm_nt(dyt, xt, dw)
+    assert rel(dw, dy.t() @ x) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_colsum_groups_and_cast(ops, dtype):
+    B, T, S, d = 3, 4, 5, 64
+    x = q(rnd(B * T * S, d, seed=1), dtype)
+    out = torch.zeros(T, d, device="cuda")
+    ops.colsum(dev(x, dtype), out, div=S, mod=T)
+    assert rel(out, x.view(B, T, S, d).sum((0, 2))) < 1e-5
+    out = torch.zeros(S, d, device="cuda")
+    ops.colsum(dev(x, dtype), out, div=1, mod=S)
+    assert rel(out, x.view(B * T, S, d).sum(0)) < 1e-5
+    out = torch.zeros(d, device="cuda")
+    ops.colsum(dev(x, dtype), out)
+    assert rel(out, x.sum(0)) < 1e-5
+    w = rnd(100, 72, seed=2)
+    wd = torch.empty(100, 72, device="cuda", dtype=dtype)
+    wt = torch.empty(72, 100, device="cuda", dtype=dtype)
+    ops.cast_weight(dev(w), wd, wt)
+    assert rel(wd, w.to(dtype).float()) == 0 and rel(wt, w.t().to(dtype).float()) == 0
+
+
+# ------------------------------------------------------------------ LayerNorm
+@pytest.mark.parametrize("odt", DTYPES)
+@pytest.mark.parametrize("rows,cols", [(50, 768), (7, 64), (33, 256), (9, 1024)])
+def test_layernorm_fwd_bwd(ops, odt, rows, cols):
+    x, g, b = rnd(rows, cols, seed=1), 1 + 0.1 * rnd(cols, seed=2), 0.1 * rnd(cols, seed=3)
+    y = torch.empty(rows, cols, device="cuda", dtype=odt)
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    X, G, Bt = dev(x), dev(g), dev(b)
+    ops.layernorm_fwd(X, G, Bt, y, mean, rstd, rows, cols, 1e-5)
+    xr = x.clone().requires_grad_(True)
+    gr, br = g.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (cols,), gr, br, 1e-5)
+    assert rel(y, ref) < TOL[odt]
+    dy = q(rnd(rows, cols, seed=4), odt)
+    ref.backward(dy)
+    dx0 = rnd(rows, cols, seed=5)
+    dx = dev(dx0.clone())
+    dg, db = torch.zeros(cols, device="cuda"), torch.zeros(cols, device="cuda")
+    ops.layernorm_bwd(dev(dy, odt), X, mean, rstd, G, dx, dg, db, rows, cols, accumulate=True)
+    assert rel(dx, dx0 + xr.grad) < 2e-5
+    assert rel(dg, gr.grad) < 2e-5 and rel(db, br.grad) < 2e-5
+
+
+def test_layernorm_add_and_gather(ops):
+    B, T, S, d = 2, 3, 5, 64
+    rows = B * T * S
+    x, g, b, temb = rnd(rows, d, seed=1), 1 + 0.1 * rnd(d, seed=2), 0.1 * rnd(d, seed=3), rnd(T, d, seed=4)
+    X = dev(x.clone())
+    y = torch.empty(rows, d, device="cuda")
+    mean, rstd = torch.empty(rows, device="cuda"), torch.empty(rows, device="cuda")
+    ops.layernorm_fwd(X, dev(g), dev(b), y, mean, rstd, rows, d, 1e-5, add=dev(temb), add_div=S, add_mod=T)
+    xa = (x.view(B, T, S, d) + temb[None, :, None, :]).view(rows, d)
+    assert rel(X, xa) < 1e-6
+    assert rel(y, F.layer_norm(xa, (d,), g, b, 1e-5)) < 2e-5
+    # gather rows n*S + off[n] (CLS / EOT pooling), mean over T in the backward
+    off = torch.tensor([0, 2, 4, 1, 3, 0], dtype=torch.int32)
+    n = B * T
+    yp = torch.empty(n, d, device="cuda")
+    mp, rp = torch.empty(n, device="cuda"), torch.empty(n, device="cuda")
+    ops.layernorm_fwd(dev(x), dev(g), dev(b), yp, mp, rp, n, d, 1e-5, in_mul=S, in_off=dev(off))
+    xr = x.clone().requires_grad_(True)
+    sel = xr.view(n, S, d)[torch.arange(n), off.long()]
+    ref = F.layer_norm(sel, (d,), g, b, 1e-5)
+    assert rel(yp, ref) < 2e-5
+    pooled = torch.empty(B, d, device="cuda")
+    ops.mean_rows(yp, pooled, B, T, d)
+    assert rel(pooled, ref.view(B, T, d).mean(1)) < 2e-5
+    dpool = rnd(B, d, seed=7)
+    ref.view(B, T, d).mean(1).backward(dpool)
+    dx = torch.zeros(rows, d, device="cuda")
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    ops.layernorm_bwd(dev(dpool), dev(x), mp, rp, dev(g), dx, dg, db, n, d, accumulate=False, dy_div=T, dy_scale=1.0 / T,
+                      in_mul=S, in_off=dev(off))
+    assert rel(dx, xr.grad) < 2e-5
+
+
+# ------------------------------------------------------------------ attention
+def attn_ref(qkv, nseq, L, H, hd, rowidx, causal, key_mask):
+    """fp32 reference on gathered rows: returns out rows and a function giving d(qkv) for a cotangent"""
+    d = H * hd
+    x = qkv.clone().requires_grad_(True)
+    g = x[rowidx.reshape(-1)].view(nseq, L, 3, H, hd)
+    qh, kh, vh = (g[:, :, i].permute(0, 2, 1, 3) for i in range(3))
+    s = (qh @ kh.transpose(-1, -2)) * hd ** -0.5
+    if causal:
+        s = s + torch.triu(torch.full((L, L), float("-inf")), 1)
+    if key_mask is not None:
+        s = s.masked_fill(key_mask[:, None, None, :] == 0, float("-inf"))
+    o = (torch.softmax(s, -1) @ vh).permute(0, 2, 1, 3).reshape(nseq, L, d)
+    return x, o
+
+
+CASES = [  # name, nseq-structure
+    dict(name="spatial_s5", B=3, T=1, S=5, H=2, hd=32, temporal=False, causal=False, mask=False),
+    dict(name="temporal_t8", B=2, T=8, S=7, H=3, hd=64, temporal=True, causal=False, mask=False),
+    dict(name="temporal_t4", B=2, T=4, S=5, H=2, hd=32, temporal=True, causal=False, mask=False),
+    dict(name="text_s16", B=5, T=1, S=16, H=2, hd=32, temporal=False, causal=True, mask=True),
+    dict(name="text_s32", B=3, T=1, S=32, H=2, hd=64, temporal=False, causal=True, mask=True),
+    dict(name="mfma_s197", B=3, T=1, S=197, H=2, hd=64, temporal=False, causal=False, mask=False),
+    dict(name="mfma_s77_causal", B=4, T=1, S=77, H=3, hd=64, temporal=False, causal=True, mask=True),
+    dict(name="mfma_s50", B=2, T=1, S=50, H=1, hd=64, temporal=False, causal=False, mask=True),
+    dict(name="mfma_s256", B=1, T=1, S=256, H=2, hd=64, temporal=False, causal=True, mask=False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_attention_fwd_bwd(ops, dtype, case):
+    B, T, S, H, hd = case["B"], case["T"], case["S"], case["H"], case["hd"]
+    d = H * hd
+    rows = B * T * S
+    qkv = q(rnd(rows, 3 * d, seed=1), dtype)
+    if case["temporal"]:
+        nseq, L = B * S, T
+        kw = dict(seq_div=S, seq_outer=T * S, seq_inner=1, tok_stride=S)
+        rowidx = torch.tensor([[(sq // S) * T * S + (sq % S) + j * S for j in range(L)] for sq in range(nseq)])
+    else:
+        nseq, L = B * T, S
+        kw = dict(seq_div=1, seq_outer=S, seq_inner=0, tok_stride=1)
+        rowidx = torch.arange(rows).view(nseq, L)
+    key_mask = None
+    if case["mask"]:
+        lens = torch.randint(max(1, L // 3), L + 1, (nseq,), generator=torch.Generator().manual_seed(3))
+        key_mask = (torch.arange(L)[None] < lens[:, None]).to(torch.int32)
+    x, oref = attn_ref(qkv, nseq, L, H, hd, rowidx, case["causal"], key_mask)
+    out = torch.zeros(rows, d, device="cuda", dtype=dtype)
+    lse = torch.empty(nseq * H * L, device="cuda")
+    QKV = dev(qkv, dtype)
+    km = dev(key_mask) if key_mask is not None else None
+    ops.attention_fwd(QKV, out, lse, nseq, L, H, hd, causal=case["causal"], key_mask=km, **kw)
+    got = out.float().cpu()[rowidx.reshape(-1)].view(nseq, L, d)
+    assert rel(got, oref) < TOL[dtype]
+    dout_seq = q(rnd(nseq, L, d, seed=9), dtype)
+    oref.backward(dout_seq)
+    dout = torch.zeros(rows, d)
+    dout[rowidx.reshape(-1)] = dout_seq.view(-1, d)
+    dqkv = torch.zeros(rows, 3 * d, device="cuda", dtype=dtype)
+    ops.attention_bwd(QKV, dev(dout, dtype), lse, dqkv, nseq, L, H, hd, causal=case["causal"], key_mask=km, **kw)
+    for i, nm in enumerate("qkv"):
+        assert rel(dqkv[:, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d]) < TOL[dtype] * 1.5, nm
+
+
+# ------------------------------------------------------------------ embeddings / tail / loss / optimizer
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_unfold_and_embed(ops, dtype):
+    B, C, T, Hh, ps, d = 2, 3, 2, 32, 16, 64
+    px5 = rnd(B, C, T, Hh, Hh, seed=1)
+    P = (Hh // ps) ** 2
+    out = torch.empty(B * T * P, C * ps * ps, device="cuda", dtype=dtype)
+    ops.unfold_patches(dev(px5), out, ps)
+    frames = px5.permute(0, 2, 1, 3, 4).reshape(B * T, C, Hh, Hh)
+    ref = F.unfold(frames, ps, stride=ps).transpose(1, 2).reshape(B * T * P, -1)
+    assert rel(out, ref.to(dtype).float()) == 0
+    out4 = torch.empty(B * T * P, C * ps * ps, device="cuda", dtype=dtype)
+    ops.unfold_patches(dev(frames.contiguous()), out4, ps)
+    assert rel(out4, ref.to(dtype).float()) == 0
+    w = rnd(d, C, ps, ps, seed=2, scale=0.02)
+    assert rel(ref @ w.view(d, -1).t(), F.conv2d(frames, w, stride=ps).flatten(2).transpose(1, 2).reshape(-1, d)) < 1e-5
+    patches = q(rnd(B * T * P, d, seed=3), dtype)
+    cls, pos = rnd(d, seed=4), rnd(P + 1, d, seed=5)
+    x = torch.empty(B * T * (P + 1), d, device="cuda")
+    ops.embed_assemble(dev(patches, dtype), dev(cls), dev(pos), x, B * T, P + 1, d)
+    refx = torch.cat([cls.expand(B * T, 1, d), patches.view(B * T, P, d)], 1) + pos[None]
+    assert rel(x, refx.view(-1, d)) < 1e-6
+
+
+def test_token_embed_and_argmax(ops):
+    B, S, d, V = 4, 16, 64, 100
+    ids = torch.randint(0, V - 1, (B, S), generator=torch.Generator().manual_seed(1))
+    ids[:, 5] = V - 1
+    ids[2, 3] = V - 1
+    tok, pos = rnd(V, d, seed=2), rnd(S, d, seed=3)
+    h = torch.empty(B * S, d, device="cuda")
+    ops.token_embed_fwd(dev(ids), dev(tok), dev(pos), h, B, S, d)
+    assert rel(h, (tok[ids] + pos[None]).view(-1, d)) < 1e-6
+    eot = torch.empty(B, dtype=torch.int32, device="cuda")
+    ops.argmax_rows(dev(ids), eot, B, S)
+    assert torch.equal(eot.cpu().long(), ids.argmax(-1))
+    dh = rnd(B * S, d, seed=4)
+    dtok, dpos = torch.zeros(V, d, device="cuda"), torch.zeros(S, d, device="cuda")
+    ops.token_embed_bwd(dev(ids), dev(dh), dtok, dpos, B, S, d)
+    ref = torch.zeros(V, d).index_add_(0, ids.view(-1), dh)
+    assert rel(dtok, ref) < 1e-5 and rel(dpos, dh.view(B, S, d).sum(0)) < 1e-5
+
+
+def test_small_linear_l2norm_ce_dropout(ops):
+    B, I, O = 10, 48, 32
+    x, w, b = rnd(B, I, seed=1), rnd(O, I, seed=2, scale=0.2), rnd(O, seed=3)
+    code = torch.tensor([0, 1, 2, 3, 4, 0, 1, 2, 3, 4])
+    y = torch.zeros(B, O, device="cuda")
+    ops.small_linear_fwd(dev(x), dev(w), dev(b), y, row_code=dev(code), code=2)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = torch.where((code == 2)[:, None], torch.zeros(B, O), F.linear(xr, wr, br))
+    assert rel(y, ref) < 1e-5
+    ops.small_linear_fwd(dev(x), dev(w), dev(b), y, row_code=dev(code), code=3, accumulate=True)
+    assert rel(y, ref + torch.where((code == 3)[:, None], torch.zeros(B, O), F.linear(x, w, b))) < 1e-5
+    dy = rnd(B, O, seed=4)
+    ref.backward(dy)
+    dx, dw, db = torch.empty(B, I, device="cuda"), torch.empty(O, I, device="cuda"), torch.empty(O, device="cuda")
+    ops.small_linear_bwd(dev(dy), dev(x), dev(w), dx, dw, db, row_code=dev(code), code=2)
+    assert rel(dx, xr.grad) < 1e-5 and rel(dw, wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    # relu variant
+    yr = torch.empty(B, O, device="cuda")
+    ops.small_linear_fwd(dev(x), dev(w), dev(b), yr, relu=True)
+    xr.grad = None
+    refr = F.linear(xr, w, b).relu()
+    assert rel(yr, refr) < 1e-5
+    refr.backward(dy)
+    ops.small_linear_bwd(dev(dy), dev(x), dev(w), dx, None, None, relu_y=yr)
+    assert rel(dx, xr.grad) < 1e-5
+    # l2 normalise * scale
+    xs = rnd(B, I, seed=5).requires_grad_(True)
+    s = math.exp(2.6592)
+    yn = torch.empty(B, I, device="cuda")
+    ops.l2norm_scale_fwd(dev(xs.detach()), yn, s)
+    refn = xs / xs.norm(p=2, dim=-1, keepdim=True) * s
+    assert rel(yn, refn) < 1e-5
+    dyn = rnd(B, I, seed=6)
+    refn.backward(dyn)
+    dxn = torch.empty(B, I, device="cuda")
+    ops.l2norm_scale_bwd(dev(dyn), dev(xs.detach()), dxn, s)
+    assert rel(dxn, xs.grad) < 1e-4
+    # cross entropy
+    logits = rnd(B, 5, seed=7).requires_grad_(True)
+    labels = torch.randint(0, 5, (B,), generator=torch.Generator().manual_seed(8))
+    loss = torch.empty(1, device="cuda")
+    dl = torch.empty(B, 5, device="cuda")
+    ops.cross_entropy(dev(logits.detach()), dev(labels), loss, dl)
+    refl = F.cross_entropy(logits, labels)
+    refl.backward()
+    assert abs(float(loss) - float(refl)) < 1e-5 and rel(dl, logits.grad) < 1e-5
+    # dropout: mask statistics, scaling and backward consistency
+    n = 1 << 16
+    xd = torch.ones(n, device="cuda")
+    yd, mk = torch.empty(n, device="cuda"), torch.empty(n, dtype=torch.uint8, device="cuda")
+    ops.dropout_fwd(xd, yd, mk, 0.1, 1234)
+    keep = mk.float().mean().item()
+    assert abs(keep - 0.9) < 0.01
+    assert torch.allclose(yd, mk.float() / 0.9)
+    dxd = torch.empty(n, device="cuda")
+    ops.dropout_bwd(xd, mk, dxd, 0.1)
+    assert torch.equal(dxd, yd)
+
+
+def test_adam_matches_torch(ops):
+    n = 10007
+    p0 = rnd(n, seed=1)
+    ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([ref], lr=1e-3, weight_decay=0.01)
+    p, m, v = dev(p0.clone()), torch.zeros(n, device="cuda"), torch.zeros(n, device="cuda")
+    for step in range(1, 4):
+        g = rnd(n, seed=10 + step)
+        ref.grad = g.clone()
+        opt.step()
+        ops.adam_step(p, dev(g * 4.0), m, v, step, 1e-3, weight_decay=0.01, grad_scale=0.25)
+    assert rel(p, ref.detach()) < 1e-6
