@@ -32,6 +32,7 @@ struct GemmArgs {
   int out_f32;            // C is fp32 (else T)
   int accumulate;         // out_f32 only: C += result
   int tiles_m, tiles_n;
+  int vec_ok;             // ldc/ldaux/pointers allow 16-byte (fp32) / 8-byte (bf16) vector epilogue accesses
 };
 
 template <typename T>
@@ -135,10 +136,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmArgs g) {
   // ---- epilogue: lane owns rows (4*lg + r) of each 16-row tile i and columns 4*li + j (j = 0..3) ----
   const int col = n0 + wn * 64 + li * 4;
   if (col >= g.N) return;
-  const bool full4 = (col + 3 < g.N);
+  const bool full4 = (col + 3 < g.N) && g.vec_ok;
   f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
   if (g.bias) {
-    if (full4) bias4 = load4(g.bias + col);
+    if (col + 3 < g.N) bias4 = load4(g.bias + col);
     else
       for (int j = 0; j < 4; ++j) if (col + j < g.N) bias4[j] = g.bias[col + j];
   }
@@ -291,14 +292,16 @@ extern "C" int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N
   const int epc = dtype == kBF16 ? 8 : 4;
   MISSM_CHECK_ARG(dtype == kBF16 || dtype == kF32, "gemm: dtype must be 0 (f32) or 1 (bf16)");
   MISSM_CHECK_ARG(K % epc == 0 && lda % epc == 0 && ldb % epc == 0, "gemm: K, lda, ldb must be multiples of 16 bytes");
-  MISSM_CHECK_ARG(ldc % 4 == 0 && (ldaux % 4 == 0), "gemm: ldc/ldaux must be multiples of 4");
   MISSM_CHECK_ARG(!(resid && !out_f32) && !(accumulate && !out_f32), "gemm: resid/accumulate need out_f32");
-  MISSM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && ((uintptr_t)C % 8 == 0), "gemm: unaligned operand");
+  MISSM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "gemm: unaligned operand");
+  MISSM_CHECK_ARG(!bias || ((uintptr_t)bias % 16 == 0), "gemm: bias must be 16-byte aligned");
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate;
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
+             ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
   dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == kBF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, block, 0, s, g);
