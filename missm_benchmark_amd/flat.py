@@ -1,0 +1,113 @@
+"""Flat fp32 parameter / gradient storage with ``nn.Parameter`` views.
+
+One allocation per tower (or fusion head) holds every parameter:  [ GEMM weight blocks | everything else ].
+  * the q/k/v projection weights (and biases) of one attention are adjacent, so the fused [3d, d] QKV GEMM,
+    its weight gradient and its bias gradient address them as one matrix / vector;
+  * the "everything else" tail (biases, LayerNorm affine, embeddings) is where gradients are accumulated with
+    atomics, so one memset per step clears exactly that range;
+  * Adam, the RCCL all-reduce and gradient clipping see a handful of large contiguous ranges instead of hundreds
+    of small tensors (sized for 288 GB HBM and per-link-bound xGMI rings: few, large messages).
+``state_dict()`` is unaffected: every reference key is still an ``nn.Parameter`` (a view into the flat buffer).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Sequence, Tuple
+
+import torch
+from torch import nn
+
+ALIGN = 64  # floats (256 B): keeps every block 16-byte aligned for vector loads and the atomics' 256-B runs
+
+
+class Block:
+    """Contiguous run of parameters (no padding inside): [(name, shape), ...]"""
+
+    def __init__(self, items: Sequence[Tuple[str, Tuple[int, ...]]], kind: str):
+        assert kind in ("mat", "vec")
+        self.items = list(items)
+        self.kind = kind
+        self.offset = -1
+        self.numel = sum(int(torch.Size(s).numel()) for _, s in items)
+
+
+class FlatStore:
+    def __init__(self, blocks: List[Block]):
+        self.blocks = [b for b in blocks if b.kind == "mat"] + [b for b in blocks if b.kind == "vec"]
+        off = 0
+        self.index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.vec_start = None
+        for b in self.blocks:
+            if b.kind == "vec" and self.vec_start is None:
+                self.vec_start = off
+            b.offset = off
+            o = off
+            for name, shape in b.items:
+                self.index[name] = (o, tuple(shape))
+                o += int(torch.Size(shape).numel())
+            off = (o + ALIGN - 1) // ALIGN * ALIGN
+        self.total = off
+        if self.vec_start is None:
+            self.vec_start = off
+        self.master = torch.zeros(self.total, dtype=torch.float32)
+        self.grad = None
+
+    # ---- views -------------------------------------------------------------------------------
+    def view(self, name: str) -> torch.Tensor:
+        o, shape = self.index[name]
+        return self.master[o:o + int(torch.Size(shape).numel())].view(shape)
+
+    def gview(self, name: str) -> torch.Tensor:
+        o, shape = self.index[name]
+        return self.grad[o:o + int(torch.Size(shape).numel())].view(shape)
+
+    def block_view(self, block: Block, buf: torch.Tensor) -> torch.Tensor:
+        return buf[block.offset:block.offset + block.numel]
+
+    def ensure_grad(self) -> torch.Tensor:
+        if self.grad is None or self.grad.device != self.master.device:
+            self.grad = torch.zeros_like(self.master)
+        return self.grad
+
+    def zero_accumulated(self):
+        """clear the range whose gradients are accumulated with atomics (everything after the GEMM weights)"""
+        g = self.ensure_grad()
+        if self.vec_start < self.total:
+            g[self.vec_start:].zero_()
+
+    def move(self, fn):
+        new = fn(self.master)
+        if new.dtype != torch.float32:
+            raise TypeError("master parameters stay fp32; pick the compute dtype with set_compute_dtype()")
+        moved = new.device != self.master.device or new.data_ptr() != self.master.data_ptr()
+        self.master = new
+        if moved:
+            self.grad = None
+        return moved
+
+
+class Node(nn.Module):
+    """Name-only container: gives parameters the reference's dotted state-dict keys; no arithmetic lives here."""
+
+    def __getitem__(self, i):
+        return getattr(self, str(i))
+
+    def __len__(self):
+        return len(self._modules)
+
+
+def attach(root: nn.Module, dotted: str, param: nn.Parameter):
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        if p not in mod._modules:
+            mod.add_module(p, Node())
+        mod = mod._modules[p]
+    mod.register_parameter(parts[-1], param)
+
+
+def get_param(root: nn.Module, dotted: str) -> nn.Parameter:
+    parts = dotted.split(".")
+    mod = root
+    for p in parts[:-1]:
+        mod = mod._modules[p]
+    return mod._parameters[parts[-1]]

@@ -1,0 +1,175 @@
+"""Drop-in for the reference's ``languagebind`` package surface used by the hot path
+(reference: languagebind/__init__.py:32-89).
+
+``LanguageBind(clip_type, use_temp=True, cache_dir=...)`` keeps the reference signature, attributes
+(``modality_encoder`` / ``modality_proj`` ModuleDicts keyed by modality plus ``'language'``, the un-registered
+``modality_scale`` dict, ``modality_config``) and ``forward(inputs) -> {modality: [B, projection_dim]}``.
+
+Differences that are build decisions (SURVEY.md sections 0.2, 8b):
+  * checkpoints cannot be fetched by NAME here (no network): ``from_pretrained`` resolves ``<cache_dir>/<name>`` or a
+    local path holding ``config.json`` + a state dict; when nothing is found the tower is built from the synthetic
+    ViT-B/16-class config below with a seeded init (what the benchmark uses) - pass ``configs=`` to override;
+  * towers run on HIP kernels in ``compute_dtype`` (bf16 default, fp32 for parity) - see ``towers.ClipTower``;
+  * image/video/audio preprocessing and the BPE tokenizer are outside this path.
+"""
+from __future__ import annotations
+
+import json
+import os
+from dataclasses import asdict
+from typing import Dict, Optional
+
+import torch
+from torch import nn
+
+from .. import nn as hnn
+from ..towers import ClipTower, TowerConfig
+
+LOGIT_SCALE_INIT = 2.6592  # configuration_image.py:303
+PROJECTION_DIM = 768       # train_ddp.py:31 feature_dims forces this
+
+
+def default_vision_config(modality: str) -> TowerConfig:
+    """Synthetic ViT-B/16 config of SURVEY.md section 0.2 (video: factorised time attention over 8 frames)."""
+    if modality == "video":
+        return TowerConfig(kind="vision", add_time_attn=True, num_frames=8)
+    return TowerConfig(kind="vision")
+
+
+def default_text_config() -> TowerConfig:
+    return TowerConfig(kind="text")
+
+
+class _Projection(nn.Module):
+    """``nn.Linear(hidden, projection_dim, bias=False)`` (image/modeling_image.py:766-767) on the HIP small-linear kernel."""
+
+    def __init__(self, in_features: int, out_features: int, seed: int):
+        super().__init__()
+        g = torch.Generator().manual_seed(seed)
+        self.weight = nn.Parameter(torch.randn(out_features, in_features, generator=g) * in_features ** -0.5)
+        self.in_features, self.out_features = in_features, out_features
+
+    def forward(self, x):
+        return hnn._LinearFn.apply(x, self.weight, None, False, None, 0)
+
+
+class LanguageBindModel(nn.Module):
+    """One modality's CLIP pair (reference ``LanguageBind<Modality>``, image/modeling_image.py:734-768): vision tower,
+    text tower, the two bias-free projections and ``logit_scale``."""
+
+    modality = "image"
+
+    def __init__(self, vision_config: Optional[TowerConfig] = None, text_config: Optional[TowerConfig] = None,
+                 projection_dim: int = PROJECTION_DIM, logit_scale_init_value: float = LOGIT_SCALE_INIT,
+                 compute_dtype: torch.dtype = torch.bfloat16, seed: int = 0, build_text: bool = True):
+        super().__init__()
+        vc = vision_config or default_vision_config(self.modality)
+        tc = text_config or default_text_config()
+        if vc.kind != "vision" or tc.kind != "text":
+            raise ValueError("config.vision_config / config.text_config are of the wrong kind")
+        self.config = {"vision_config": asdict(vc), "text_config": asdict(tc), "projection_dim": projection_dim,
+                       "logit_scale_init_value": logit_scale_init_value}
+        self.vision_model = ClipTower(vc, compute_dtype, seed=seed)
+        self.visual_projection = _Projection(vc.hidden_size, projection_dim, seed + 1)
+        if build_text:
+            self.text_model = ClipTower(tc, compute_dtype, seed=seed + 2)
+            self.text_projection = _Projection(tc.hidden_size, projection_dim, seed + 3)
+        self.logit_scale = nn.Parameter(torch.tensor(float(logit_scale_init_value)))
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, cache_dir: Optional[str] = None, **kw):
+        """Local-only resolution (there is no network): a directory with ``config.json`` and ``pytorch_model.bin`` /
+        ``model.pt``.  Falls back to the synthetic seeded model when the checkpoint is not on disk."""
+        for root in (pretrained_model_name_or_path, os.path.join(cache_dir or ".", pretrained_model_name_or_path)):
+            cfg_path = os.path.join(root, "config.json")
+            if os.path.isdir(root) and os.path.exists(cfg_path):
+                raw = json.load(open(cfg_path))
+                vc = TowerConfig(kind="vision", **{k: v for k, v in raw.get("vision_config", {}).items() if k in TowerConfig.__dataclass_fields__ and k != "kind"})
+                tc = TowerConfig(kind="text", **{k: v for k, v in raw.get("text_config", {}).items() if k in TowerConfig.__dataclass_fields__ and k != "kind"})
+                kw.pop("text_config", None)
+                kw.pop("projection_dim", None)
+                model = cls(vc, tc, raw.get("projection_dim", PROJECTION_DIM), raw.get("logit_scale_init_value", LOGIT_SCALE_INIT), **kw)
+                for fn in ("pytorch_model.bin", "model.pt", "model.pth"):
+                    p = os.path.join(root, fn)
+                    if os.path.exists(p):
+                        model.load_state_dict(torch.load(p, map_location="cpu"), strict=False)
+                        break
+                return model
+        return cls(**kw)
+
+
+def _model_class(modality: str):
+    return type(f"LanguageBind{modality.capitalize()}", (LanguageBindModel,), {"modality": modality})
+
+
+LanguageBindImage, LanguageBindVideo, LanguageBindDepth, LanguageBindAudio, LanguageBindThermal = (
+    _model_class(m) for m in ("image", "video", "depth", "audio", "thermal"))
+
+model_dict = {"thermal": LanguageBindThermal, "image": LanguageBindImage, "video": LanguageBindVideo,
+              "depth": LanguageBindDepth, "audio": LanguageBindAudio}
+config_dict = {m: TowerConfig for m in model_dict}
+
+
+class _OutOfScope:
+    def __init__(self, what):
+        self.what = what
+
+    def __call__(self, *a, **k):
+        raise NotImplementedError(f"{self.what} is host-side preprocessing outside the MI355X hot path (SURVEY.md 2.1); "
+                                  "feed tensors (pixel_values / input_ids) directly")
+
+    from_pretrained = __call__
+
+
+transform_dict = {m: _OutOfScope(f"{m} processor") for m in model_dict}
+LanguageBindImageTokenizer = _OutOfScope("LanguageBindImageTokenizer")
+
+
+class LanguageBind(nn.Module):
+    def __init__(self, clip_type, use_temp=True, cache_dir="./cache_dir", *, configs: Optional[Dict[str, TowerConfig]] = None,
+                 text_config: Optional[TowerConfig] = None, projection_dim: int = PROJECTION_DIM,
+                 compute_dtype: torch.dtype = torch.bfloat16, seed: int = 0):
+        super().__init__()
+        self.use_temp = use_temp
+        encoders, projs = {}, {}
+        self.modality_scale = {}   # plain dict on purpose: un-registered in the reference too (languagebind/__init__.py:60,67)
+        self.modality_config = {}
+        items = list(clip_type.items())
+        model = None
+        for i, (k, v) in enumerate(items):
+            last = i == len(items) - 1
+            kw = dict(compute_dtype=compute_dtype, seed=seed + 10 * i, build_text=last)
+            if configs and k in configs:
+                model = model_dict[k](configs[k], text_config, projection_dim, **kw)
+            else:
+                model = model_dict[k].from_pretrained(f"LanguageBind/{v}", cache_dir=cache_dir, text_config=text_config,
+                                                      projection_dim=projection_dim, **kw)
+            encoders[k] = model.vision_model
+            projs[k] = model.visual_projection
+            self.modality_scale[k] = model.logit_scale
+            self.modality_config[k] = model.config
+        # the text tower always comes from the LAST loaded modality model (languagebind/__init__.py:69-70)
+        encoders["language"] = model.text_model
+        projs["language"] = model.text_projection
+        self.modality_encoder = nn.ModuleDict(encoders)
+        self.modality_proj = nn.ModuleDict(projs)
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        for t in self.modality_encoder.values():
+            t.set_compute_dtype(dtype)
+        return self
+
+    def forward(self, inputs):
+        outputs = {}
+        for key, value in inputs.items():
+            pooled = self.modality_encoder[key](**value)[1]
+            emb = self.modality_proj[key](pooled)
+            scale = 1.0
+            if self.use_temp and key != "language":
+                scale = float(self.modality_scale[key].detach().exp())
+            outputs[key] = hnn.l2norm_scale(emb, scale)
+        return outputs
+
+
+def to_device(x, device):
+    return {k: v.to(device) for k, v in x.items()}

@@ -1,0 +1,214 @@
+"""Small HIP-backed modules for the projection / fusion tail (all fp32, launch-bound).
+
+Each is an ``nn.Module`` holding ordinary ``nn.Parameter``s (so ``state_dict()`` keys match the reference's
+``nn.Linear`` / ``nn.LayerNorm`` children) whose forward/backward are ``libmissm_hip.so`` launches wrapped in an
+``autograd.Function``.  No torch arithmetic is used.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Sequence
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+
+
+def _gpu(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise _lib.MissmError(f"{what}: runs only on an MI355X; there is no CPU fallback")
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, relu, row_code, code):
+        _gpu(x, "HipLinear")
+        x = x.contiguous().float()
+        y = torch.empty(x.shape[0], w.shape[0], device=x.device, dtype=torch.float32)
+        ops.small_linear_fwd(x, w, b, y, relu=relu, row_code=row_code, code=code)
+        ctx.save_for_backward(x, w, y if relu else None, row_code)
+        ctx.code, ctx.has_bias = code, b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y, row_code = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dw = torch.empty_like(w)
+        db = torch.empty(w.shape[0], device=w.device, dtype=torch.float32) if ctx.has_bias else None
+        ops.small_linear_bwd(dy, x, w, dx, dw, db, relu_y=y, row_code=row_code, code=ctx.code)
+        return dx, dw, db, None, None, None
+
+
+class HipLinear(nn.Module):
+    """nn.Linear stand-in: y = x W^T + b, optional fused ReLU, optional zeroing of rows whose code matches."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, relu: bool = False):
+        super().__init__()
+        if in_features % 4:
+            raise ValueError("in_features must be a multiple of 4")
+        self.in_features, self.out_features, self.relu = in_features, out_features, relu
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        self.bias = nn.Parameter(torch.empty(out_features)) if bias else None
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))
+        if self.bias is not None:
+            bound = 1 / math.sqrt(self.in_features)
+            nn.init.uniform_(self.bias, -bound, bound)
+
+    def forward(self, x, row_code: Optional[torch.Tensor] = None, code: int = 0):
+        return _LinearFn.apply(x, self.weight, self.bias, self.relu, row_code, code)
+
+
+class _SumLinearFn(torch.autograd.Function):
+    """z = sum_m where(missing == code_m, 0, e_m W_m^T + b_m): the cross-modal fusion projection in one pass."""
+
+    @staticmethod
+    def forward(ctx, missing, codes, n, *tensors):
+        xs, ws, bs = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        _gpu(xs[0], "fusion projection")
+        xs = tuple(x.contiguous().float() for x in xs)
+        z = torch.empty(xs[0].shape[0], ws[0].shape[0], device=xs[0].device, dtype=torch.float32)
+        for i in range(n):
+            ops.small_linear_fwd(xs[i], ws[i], bs[i], z, row_code=missing, code=codes[i], accumulate=i > 0)
+        ctx.save_for_backward(missing, *xs, *ws)
+        ctx.codes, ctx.n = codes, n
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        n = ctx.n
+        missing = ctx.saved_tensors[0]
+        xs, ws = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:]
+        dz = dz.contiguous()
+        dxs, dws, dbs = [], [], []
+        for i in range(n):
+            dx, dw = torch.empty_like(xs[i]), torch.empty_like(ws[i])
+            db = torch.empty(ws[i].shape[0], device=dz.device, dtype=torch.float32)
+            ops.small_linear_bwd(dz, xs[i], ws[i], dx, dw, db, row_code=missing, code=ctx.codes[i])
+            dxs.append(dx); dws.append(dw); dbs.append(db)
+        return (None, None, None, *dxs, *dws, *dbs)
+
+
+def fused_modal_sum(missing_index: torch.Tensor, codes: Sequence[int], xs, linears: Sequence[HipLinear]):
+    n = len(xs)
+    return _SumLinearFn.apply(missing_index.contiguous(), tuple(int(c) for c in codes), n, *xs, *[l.weight for l in linears],
+                              *[l.bias for l in linears])
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, eps):
+        _gpu(x, "HipLayerNorm")
+        x = x.contiguous().float()
+        rows, cols = x.shape
+        y = torch.empty_like(x)
+        mean, rstd = torch.empty(rows, device=x.device), torch.empty(rows, device=x.device)
+        ops.layernorm_fwd(x, w, b, y, mean, rstd, rows, cols, eps)
+        ctx.save_for_backward(x, w, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, mean, rstd = ctx.saved_tensors
+        rows, cols = x.shape
+        dx = torch.empty_like(x)
+        dw, db = torch.zeros_like(w), torch.zeros_like(w)
+        ops.layernorm_bwd(dy.contiguous(), x, mean, rstd, w, dx, dw, db, rows, cols, accumulate=False)
+        return dx, dw, db, None
+
+
+class HipLayerNorm(nn.Module):
+    def __init__(self, normalized_shape: int, eps: float = 1e-5):
+        super().__init__()
+        if normalized_shape % 4 or normalized_shape > 2048:
+            raise ValueError("normalized_shape must be a multiple of 4 and <= 2048")
+        self.normalized_shape, self.eps = normalized_shape, eps
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
+
+    def forward(self, x):
+        return _LayerNormFn.apply(x, self.weight, self.bias, self.eps)
+
+
+class _DropoutFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        mask = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+        ops.dropout_fwd(x, y, mask, p, seed)
+        ctx.save_for_backward(mask)
+        ctx.p = p
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (mask,) = ctx.saved_tensors
+        dx = torch.empty_like(dy)
+        ops.dropout_bwd(dy.contiguous(), mask, dx, ctx.p)
+        return dx, None, None
+
+
+class HipDropout(nn.Module):
+    """nn.Dropout stand-in (src/model/baseline.py:34) with a counter-based generator seeded from torch's RNG."""
+
+    def __init__(self, p: float = 0.1):
+        super().__init__()
+        self.p = float(p)
+
+    def forward(self, x):
+        if not self.training or self.p == 0.0:
+            return x
+        seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
+        return _DropoutFn.apply(x, self.p, seed)
+
+
+class _L2NormScaleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        ops.l2norm_scale_fwd(x, y, scale)
+        ctx.save_for_backward(x)
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        ops.l2norm_scale_bwd(dy.contiguous(), x, dx, ctx.scale)
+        return dx, None
+
+
+def l2norm_scale(x: torch.Tensor, scale: float) -> torch.Tensor:
+    return _L2NormScaleFn.apply(x, float(scale))
+
+
+class _CrossEntropyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _gpu(logits, "HipCrossEntropyLoss")
+        logits = logits.contiguous().float()
+        loss = torch.empty(1, device=logits.device, dtype=torch.float32)
+        dl = torch.empty_like(logits)
+        ops.cross_entropy(logits, labels.contiguous(), loss, dl)
+        ctx.save_for_backward(dl)
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+class HipCrossEntropyLoss(nn.Module):
+    """nn.CrossEntropyLoss() (mean reduction, train_ddp.py:88): loss and d(logits) from one launch."""
+
+    def forward(self, logits, labels):
+        return _CrossEntropyFn.apply(logits, labels)

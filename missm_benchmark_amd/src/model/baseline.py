@@ -1,0 +1,84 @@
+"""Drop-in for the reference's ``src.model.baseline`` (reference: src/model/baseline.py:8,27-61,421-453).
+
+``finetune_model(args, output_dims, encoder_model)`` keeps the reference constructor / attributes / forward:
+``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
+fusion_dim, dropout_prob, fusion_type``.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
+state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
+
+``missing_type_index`` extends the reference's 4 codes with depth/thermal (codes 0-4 unchanged) - the reference's towers
+for those modalities exist but its fusion table does not list them.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from ... import nn as hnn
+from ...languagebind import LanguageBind, LanguageBindImageTokenizer, to_device, transform_dict  # noqa: F401  (reference re-exports)
+
+missing_type_index = {"language": 1, "video": 2, "audio": 3, "image": 4, "depth": 5, "thermal": 6}
+
+
+class Head(nn.Module):
+    """Linear -> ReLU -> Dropout -> Linear kept under ``head.{0,3}`` like the reference's nn.Sequential."""
+
+    def __init__(self, args, input_dims, output_dims):
+        super().__init__()
+        stages = nn.Module()
+        stages.add_module("0", hnn.HipLinear(input_dims, args.fusion_dim, relu=True))   # ReLU fused into the launch
+        stages.add_module("2", hnn.HipDropout(args.dropout_prob))
+        stages.add_module("3", hnn.HipLinear(args.fusion_dim, output_dims))
+        self.head = stages
+
+    def forward(self, inputs):
+        m = self.head._modules
+        return m["3"](m["2"](m["0"](inputs)))
+
+
+class _FusionBase(nn.Module):
+    def __init__(self, args, output_dims, head_in):
+        super().__init__()
+        self.modality_types = list(args.modality_types)
+        unknown = [m for m in self.modality_types if m not in missing_type_index]
+        if unknown:
+            raise KeyError(f"no missing-type code for {unknown}")
+        self.modal_proj = nn.ModuleDict({m: hnn.HipLinear(args.feature_dims, args.fusion_dim) for m in self.modality_types})
+        self.norm = hnn.HipLayerNorm(head_in)
+        self.head = Head(args, head_in, output_dims)
+
+    def _codes(self):
+        return [missing_type_index[m] for m in self.modality_types]
+
+
+class modal_sum(_FusionBase):
+    """Arithmetic composition: sum of the present modalities' projections (reference :43-61)."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim)
+
+    def forward(self, batch, missing_index):
+        z = hnn.fused_modal_sum(missing_index, self._codes(), [batch[m] for m in self.modality_types],
+                                [self.modal_proj[m] for m in self.modality_types])
+        return self.head(self.norm(z))
+
+
+_NOT_YET = ("concat", "regression", "retrieval", "intra_attention", "inter_attention", "graph_fusion", "unified_graph",
+            "dedicated_dnn", "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
+
+
+class finetune_model(nn.Module):
+    def __init__(self, args, output_dims, encoder_model):
+        super().__init__()
+        self.encoder = encoder_model
+        self.fusion_type = args.fusion_type
+        if args.fusion_type == "sum":
+            self.fusion = modal_sum(args, output_dims)
+        elif args.fusion_type in _NOT_YET:
+            raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
+        else:
+            raise ValueError(f"unknown fusion_type {args.fusion_type!r}")
+
+    def forward(self, data, missing_index):
+        embedding = self.encoder(data)
+        return self.fusion(embedding, missing_index)

@@ -1,0 +1,529 @@
+"""CLIP vision / text towers of LanguageBind on the HIP kernels (host-side orchestration, Python like the reference).
+
+Mirrors ``CLIPVisionTransformer`` / ``CLIPTextTransformer`` of the reference
+(languagebind/image/modeling_image.py:458-532,596-672; languagebind/video/modeling_video.py:702-784): same
+constructor config fields, same ``forward`` keywords, same ``(last_hidden_state, pooled_output)`` tuple, same
+``ValueError`` texts and the same state-dict keys (incl. the misspelt ``pre_layrnorm``).  The arithmetic is NOT torch:
+every op is a launch into ``libmissm_hip.so``; torch only owns the buffers and the stream.
+
+Precision: parameters, the residual stream, LayerNorm statistics and parameter gradients are fp32.  GEMM / attention
+operands are ``compute_dtype`` (bf16 for throughput, fp32 for the 1e-3 parity gate) - one kernel source, two
+instantiations.  The backward is hand-written (no autograd inside a tower): one ``autograd.Function`` per tower.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import List, Optional, Tuple
+
+import torch
+from torch import nn
+
+from . import _lib, ops
+from .flat import Block, FlatStore, Node, attach
+
+_GRAD_MODE = "direct"  # "direct": kernels write parameter gradients in place; "autograd": returned through autograd (DDP-wrap safe)
+
+
+def set_grad_mode(mode: str):
+    global _GRAD_MODE
+    assert mode in ("direct", "autograd")
+    _GRAD_MODE = mode
+
+
+@dataclass
+class TowerConfig:
+    kind: str = "vision"                 # "vision" | "text"
+    hidden_size: int = 768
+    intermediate_size: int = 3072
+    num_hidden_layers: int = 12
+    num_attention_heads: int = 12
+    layer_norm_eps: float = 1e-5
+    hidden_act: str = "quick_gelu"
+    # vision (configuration_image.py:181-232)
+    num_channels: int = 3
+    image_size: int = 224
+    patch_size: int = 16
+    add_time_attn: bool = False
+    num_frames: int = 1
+    temporal_mlp: bool = False
+    # text (configuration_image.py:70-105)
+    vocab_size: int = 49408
+    max_position_embeddings: int = 77
+
+    @property
+    def seq_len(self) -> int:
+        return (self.image_size // self.patch_size) ** 2 + 1 if self.kind == "vision" else self.max_position_embeddings
+
+
+def _r64(n: int) -> int:
+    return (n + 63) // 64 * 64
+
+
+class ClipTower(nn.Module):
+    def __init__(self, config: TowerConfig, compute_dtype: torch.dtype = torch.bfloat16, seed: Optional[int] = None):
+        super().__init__()
+        c = config
+        if c.hidden_act not in ops.ACT_CODE:
+            raise ValueError(f"unsupported hidden_act {c.hidden_act!r}")
+        if c.temporal_mlp:
+            raise NotImplementedError("temporal_mlp (image-family add_time_attn branch) is not on the HIP path yet")
+        if c.hidden_size % c.num_attention_heads or (c.hidden_size // c.num_attention_heads) % 8:
+            raise ValueError("head_dim must be a multiple of 8")
+        if c.kind == "vision" and (c.patch_size % 4 or c.image_size % c.patch_size):
+            raise ValueError("patch_size must be a multiple of 4 and divide image_size")
+        self.config = c
+        self.compute_dtype = compute_dtype
+        d, f = c.hidden_size, c.intermediate_size
+        blocks: List[Block] = []
+        if c.kind == "vision":
+            blocks.append(Block([("embeddings.patch_embedding.weight", (d, c.num_channels, c.patch_size, c.patch_size))], "mat"))
+            blocks.append(Block([("embeddings.class_embedding", (d,)), ("embeddings.position_embedding.weight", (c.seq_len, d)),
+                                 ("pre_layrnorm.weight", (d,)), ("pre_layrnorm.bias", (d,))], "vec"))
+        else:
+            blocks.append(Block([("embeddings.token_embedding.weight", (c.vocab_size, d)),
+                                 ("embeddings.position_embedding.weight", (c.max_position_embeddings, d))], "vec"))
+        self._mat_blocks = {}
+        for i in range(c.num_hidden_layers):
+            p = f"encoder.layers.{i}"
+            vec = []
+            if c.add_time_attn:
+                b = Block([(f"{p}.temporal_attn.{n}_proj.weight", (d, d)) for n in "qkv"], "mat"); blocks.append(b)
+                self._mat_blocks[f"{p}.tqkv"] = b
+                b = Block([(f"{p}.temporal_attn.out_proj.weight", (d, d))], "mat"); blocks.append(b)
+                self._mat_blocks[f"{p}.tout"] = b
+                vec += [(f"{p}.temporal_embedding", (1, c.num_frames, d))]
+                vec += [(f"{p}.temporal_attn.{n}_proj.bias", (d,)) for n in "qkv"]
+                vec += [(f"{p}.temporal_attn.out_proj.bias", (d,)), (f"{p}.temporal_layer_norm1.weight", (d,)),
+                        (f"{p}.temporal_layer_norm1.bias", (d,))]
+            b = Block([(f"{p}.self_attn.{n}_proj.weight", (d, d)) for n in "qkv"], "mat"); blocks.append(b)
+            self._mat_blocks[f"{p}.qkv"] = b
+            for key, name, shape in (("out", "self_attn.out_proj.weight", (d, d)), ("fc1", "mlp.fc1.weight", (f, d)),
+                                     ("fc2", "mlp.fc2.weight", (d, f))):
+                b = Block([(f"{p}.{name}", shape)], "mat"); blocks.append(b)
+                self._mat_blocks[f"{p}.{key}"] = b
+            vec += [(f"{p}.self_attn.{n}_proj.bias", (d,)) for n in "qkv"]
+            vec += [(f"{p}.self_attn.out_proj.bias", (d,)), (f"{p}.layer_norm1.weight", (d,)), (f"{p}.layer_norm1.bias", (d,)),
+                    (f"{p}.mlp.fc1.bias", (f,)), (f"{p}.mlp.fc2.bias", (d,)), (f"{p}.layer_norm2.weight", (d,)),
+                    (f"{p}.layer_norm2.bias", (d,))]
+            blocks.append(Block(vec, "vec"))
+        tail = "post_layernorm" if c.kind == "vision" else "final_layer_norm"
+        blocks.append(Block([(f"{tail}.weight", (d,)), (f"{tail}.bias", (d,))], "vec"))
+        if c.kind == "vision":
+            self._mat_blocks["patch"] = blocks[0]
+        self._store = FlatStore(blocks)
+        self._param_names = list(self._store.index.keys())
+        for name in self._param_names:
+            attach(self, name, nn.Parameter(self._store.view(name)))
+        n_pos = c.seq_len
+        self.embeddings.register_buffer("position_ids", torch.arange(n_pos).expand((1, -1)).clone(), persistent=False)
+        self._anchor = torch.zeros((), requires_grad=True)
+        self._shadow = {}
+        self._shadow_version = None
+        self._lp = None
+        self.reset_parameters(0 if seed is None else seed)
+
+    # ------------------------------------------------------------------ parameters
+    def named_flat(self):
+        return self._store
+
+    @torch.no_grad()
+    def reset_parameters(self, seed: int):
+        """Seeded init with the std's of CLIPPreTrainedModel._init_weights (image/modeling_image.py:179-230)."""
+        c = self.config
+        g = torch.Generator().manual_seed(seed)
+        d, L = c.hidden_size, c.num_hidden_layers
+        in_std, out_std, fc_std = d ** -0.5 * (2 * L) ** -0.5, d ** -0.5, (2 * d) ** -0.5
+        cpu = {}
+        for name in self._param_names:
+            shape = self._store.index[name][1]
+            leaf = name.split(".")[-2] + "." + name.split(".")[-1] if "." in name else name
+            if name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+                t = torch.ones(shape)
+            elif name.endswith(".bias"):
+                t = torch.zeros(shape)
+            elif "class_embedding" in name or "temporal_embedding" in name:
+                t = torch.randn(shape, generator=g) * d ** -0.5
+            elif "embedding" in name:
+                t = torch.randn(shape, generator=g) * 0.02
+            elif leaf.startswith(("q_proj", "k_proj", "v_proj")) or leaf.startswith("fc2"):
+                t = torch.randn(shape, generator=g) * in_std
+            elif leaf.startswith("out_proj"):
+                t = torch.randn(shape, generator=g) * out_std
+            elif leaf.startswith("fc1"):
+                t = torch.randn(shape, generator=g) * fc_std
+            else:
+                raise AssertionError(name)
+            cpu[name] = t
+        for name, t in cpu.items():
+            self._store.view(name).copy_(t)
+        self.mark_dirty()
+
+    def _rebind(self):
+        for name in self._param_names:
+            p = self.get_parameter(name)
+            p.data = self._store.view(name)
+            p.grad = None
+        self._shadow.clear()
+        self._shadow_version = None
+        self._lp = None
+
+    def _apply(self, fn, recurse=True):
+        self._store.move(fn)
+        self._rebind()
+        for m in self.modules():
+            for k, b in m._buffers.items():
+                if b is not None:
+                    m._buffers[k] = fn(b)
+        self._anchor = torch.zeros((), requires_grad=True, device=self._store.master.device)
+        return self
+
+    def set_compute_dtype(self, dtype: torch.dtype):
+        assert dtype in (torch.float32, torch.bfloat16)
+        self.compute_dtype = dtype
+        self._shadow.clear()
+        self._shadow_version = None
+        self._lp = None
+        return self
+
+    def mark_dirty(self):
+        self._shadow_version = None
+
+    def flat_master(self) -> torch.Tensor:
+        return self._store.master
+
+    def flat_grad(self) -> torch.Tensor:
+        return self._store.ensure_grad()
+
+    def _refresh_shadows(self):
+        """(re)build the compute-dtype copies W [N,K] and W^T [K,N] of every GEMM weight block"""
+        st = self._store
+        T = self.compute_dtype
+        for key, b in self._mat_blocks.items():
+            K = st.index[b.items[0][0]][1]
+            n_out = sum(s[0] for _, s in b.items)
+            k_in = b.numel // n_out
+            src = st.block_view(b, st.master).view(n_out, k_in)
+            if key not in self._shadow:
+                w = src if T == torch.float32 else torch.empty(n_out, k_in, device=src.device, dtype=T)
+                wt = torch.empty(k_in, n_out, device=src.device, dtype=T)
+                self._shadow[key] = (w, wt)
+            w, wt = self._shadow[key]
+            ops.cast_weight(src, None if T == torch.float32 else w, wt)
+        self._shadow_version = st.master._version
+
+    def _ensure_ready(self):
+        st = self._store
+        if not st.master.is_cuda:
+            raise _lib.MissmError("ClipTower runs only on an MI355X (move the module to cuda); there is no CPU fallback")
+        if self._shadow_version != st.master._version or not self._shadow:
+            self._refresh_shadows()
+        if self._lp is None:
+            self._build_layer_params()
+
+    def _build_layer_params(self):
+        st, c = self._store, self.config
+        d = c.hidden_size
+        self._lp = []
+        st.ensure_grad()
+        for i in range(c.num_hidden_layers):
+            p = f"encoder.layers.{i}"
+            L = SimpleNamespace()
+
+            def vec3(prefix, buf):
+                o, _ = st.index[f"{p}.{prefix}.q_proj.bias"]
+                return buf[o:o + 3 * d]
+
+            L.qkv_b, L.g_qkv_b = vec3("self_attn", st.master), vec3("self_attn", st.grad)
+            for nm, key in (("out_b", "self_attn.out_proj.bias"), ("ln1_w", "layer_norm1.weight"), ("ln1_b", "layer_norm1.bias"),
+                            ("fc1_b", "mlp.fc1.bias"), ("fc2_b", "mlp.fc2.bias"), ("ln2_w", "layer_norm2.weight"),
+                            ("ln2_b", "layer_norm2.bias")):
+                setattr(L, nm, st.view(f"{p}.{key}")); setattr(L, "g_" + nm, st.gview(f"{p}.{key}"))
+            for key in ("qkv", "out", "fc1", "fc2"):
+                b = self._mat_blocks[f"{p}.{key}"]
+                n_out = sum(s[0] for _, s in b.items)
+                setattr(L, "g_" + key + "_w", st.block_view(b, st.grad).view(n_out, b.numel // n_out))
+            if c.add_time_attn:
+                L.tqkv_b, L.g_tqkv_b = vec3("temporal_attn", st.master), vec3("temporal_attn", st.grad)
+                for nm, key in (("tout_b", "temporal_attn.out_proj.bias"), ("tln_w", "temporal_layer_norm1.weight"),
+                                ("tln_b", "temporal_layer_norm1.bias")):
+                    setattr(L, nm, st.view(f"{p}.{key}")); setattr(L, "g_" + nm, st.gview(f"{p}.{key}"))
+                L.temb = st.view(f"{p}.temporal_embedding").view(c.num_frames, d)
+                L.g_temb = st.gview(f"{p}.temporal_embedding").view(c.num_frames, d)
+                for key in ("tqkv", "tout"):
+                    b = self._mat_blocks[f"{p}.{key}"]
+                    n_out = sum(s[0] for _, s in b.items)
+                    setattr(L, "g_" + key + "_w", st.block_view(b, st.grad).view(n_out, b.numel // n_out))
+            self._lp.append(L)
+
+    def _w(self, key):
+        return self._shadow[key]
+
+    # ------------------------------------------------------------------ public forward (reference signature)
+    def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, *,
+                input_ids=None, attention_mask=None, position_ids=None):
+        c = self.config
+        if c.kind == "text" and input_ids is None and pixel_values is not None and pixel_values.dtype in (torch.int64, torch.int32):
+            input_ids, pixel_values = pixel_values, None  # positional call of the text tower
+        if c.kind == "vision":
+            if pixel_values is None:
+                raise ValueError("You have to specify pixel_values")
+            inputs = (pixel_values,)
+        else:
+            if input_ids is None:
+                raise ValueError("You have to specify input_ids")
+            inputs = (input_ids, attention_mask)
+        self._ensure_ready()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        params = tuple(self.get_parameter(n) for n in self._param_names) if (need_grad and _GRAD_MODE == "autograd") else ()
+        last, pooled = _TowerFn.apply(self._anchor, self, inputs, need_grad, *params)
+        return (last, pooled)
+
+    # ------------------------------------------------------------------ forward implementation
+    def _forward_impl(self, inputs, save: bool):
+        c, st, T = self.config, self._store, self.compute_dtype
+        dev = st.master.device
+        d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
+        hd = d // H
+        S = c.seq_len
+        s = SimpleNamespace(layers=[], save=save)
+        f32 = dict(device=dev, dtype=torch.float32)
+        if c.kind == "vision":
+            px = inputs[0]
+            if px.dim() == 7:
+                b_new, pair_new, Tf, bs_new, ch, hh, ww = px.shape
+                B = b_new * pair_new * bs_new
+                px = px.reshape(B * Tf, ch, hh, ww)
+            elif px.dim() == 5:
+                B, _, Tf, _, _ = px.shape
+            elif px.dim() == 4:
+                B, Tf = px.shape[0], 1
+            else:
+                raise ValueError(f"pixel_values must be 4-D, 5-D or 7-D, got {px.dim()}-D")
+            px = px.to(device=dev, dtype=torch.float32)
+            if px.stride(-1) != 1 or px.stride(-2) != px.shape[-1]:
+                px = px.contiguous()
+            if px.shape[-1] != c.image_size or px.shape[-2] != c.image_size or px.shape[1] != c.num_channels:
+                raise ValueError(f"pixel_values spatial/channel shape {tuple(px.shape)} does not match the tower config")
+            if c.add_time_attn and Tf != c.num_frames:
+                raise ValueError(f"time attention is configured for {c.num_frames} frames, got {Tf}")
+            N = B * Tf
+            P = S - 1
+            Kp = c.num_channels * c.patch_size ** 2
+            U = torch.empty(N * P, Kp, device=dev, dtype=T)
+            ops.unfold_patches(px, U, c.patch_size)
+            pe = torch.empty(N * P, d, device=dev, dtype=T)
+            ops.gemm_nt(U, self._w("patch")[0], pe)
+            x0 = torch.empty(N * S, d, **f32)
+            ops.embed_assemble(pe, st.view("embeddings.class_embedding"), st.view("embeddings.position_embedding.weight"), x0, N, S, d)
+            h = torch.empty(N * S, d, **f32)
+            m0, r0 = torch.empty(N * S, **f32), torch.empty(N * S, **f32)
+            ops.layernorm_fwd(x0, st.view("pre_layrnorm.weight"), st.view("pre_layrnorm.bias"), h, m0, r0, N * S, d, c.layer_norm_eps)
+            s.emb = (U, x0, m0, r0) if save else None
+            causal, key_mask = False, None
+        else:
+            ids, amask = inputs
+            ids = ids.to(dev).view(-1, ids.shape[-1]).contiguous().long()
+            B, Sx = ids.shape
+            if Sx > c.max_position_embeddings:
+                raise ValueError("sequence longer than max_position_embeddings")
+            S, Tf, N = Sx, 1, B
+            h = torch.empty(N * S, d, **f32)
+            ops.token_embed_fwd(ids, st.view("embeddings.token_embedding.weight"), st.view("embeddings.position_embedding.weight"), h, B, S, d)
+            causal = True
+            key_mask = amask.to(dev).view(B, S).to(torch.int32).contiguous() if amask is not None else None
+            s.ids = ids
+        rows = N * S
+        s.geom = (B, Tf, N, S, rows)
+        act = ops.ACT_CODE[c.hidden_act]
+        for i in range(c.num_hidden_layers):
+            L = self._lp[i]
+            pfx = f"encoder.layers.{i}"
+            rec = SimpleNamespace()
+            if c.add_time_attn:
+                xt = torch.empty(rows, d, device=dev, dtype=T)
+                mt, rt = torch.empty(rows, **f32), torch.empty(rows, **f32)
+                ops.layernorm_fwd(h, L.tln_w, L.tln_b, xt, mt, rt, rows, d, c.layer_norm_eps,
+                                  add=L.temb if Tf != 1 else None, add_div=S, add_mod=Tf)
+                qkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
+                ops.gemm_nt(xt, self._w(f"{pfx}.tqkv")[0], qkv, bias=L.tqkv_b)
+                ctx = torch.empty(rows, d, device=dev, dtype=T)
+                lse = torch.empty(B * S * H * Tf, **f32)
+                ops.attention_fwd(qkv, ctx, lse, B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
+                h2 = torch.empty(rows, d, **f32)
+                ops.gemm_nt(ctx, self._w(f"{pfx}.tout")[0], h2, bias=L.tout_b, resid=h)
+                if save:
+                    rec.t = (h, xt, mt, rt, qkv, ctx, lse)
+                h = h2
+            x1 = torch.empty(rows, d, device=dev, dtype=T)
+            m1, r1 = torch.empty(rows, **f32), torch.empty(rows, **f32)
+            ops.layernorm_fwd(h, L.ln1_w, L.ln1_b, x1, m1, r1, rows, d, c.layer_norm_eps)
+            qkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
+            ops.gemm_nt(x1, self._w(f"{pfx}.qkv")[0], qkv, bias=L.qkv_b)
+            ctx = torch.empty(rows, d, device=dev, dtype=T)
+            lse = torch.empty(N * H * S, **f32)
+            ops.attention_fwd(qkv, ctx, lse, N, S, H, hd, causal=causal, key_mask=key_mask)
+            h2 = torch.empty(rows, d, **f32)
+            ops.gemm_nt(ctx, self._w(f"{pfx}.out")[0], h2, bias=L.out_b, resid=h)
+            x2 = torch.empty(rows, d, device=dev, dtype=T)
+            m2, r2 = torch.empty(rows, **f32), torch.empty(rows, **f32)
+            ops.layernorm_fwd(h2, L.ln2_w, L.ln2_b, x2, m2, r2, rows, d, c.layer_norm_eps)
+            a = torch.empty(rows, f, device=dev, dtype=T)
+            u = torch.empty(rows, f, device=dev, dtype=T) if save else None
+            ops.gemm_nt(x2, self._w(f"{pfx}.fc1")[0], a, bias=L.fc1_b, act=act, aux_out=u)
+            h3 = torch.empty(rows, d, **f32)
+            ops.gemm_nt(a, self._w(f"{pfx}.fc2")[0], h3, bias=L.fc2_b, resid=h2)
+            if save:
+                rec.a = (h, x1, m1, r1, qkv, ctx, lse)
+                rec.m = (h2, x2, m2, r2, u, a)
+                s.layers.append(rec)
+            h = h3
+        s.key_mask, s.causal = key_mask, causal
+        # pooling (+ final LayerNorm)
+        if c.kind == "vision":
+            pl = torch.empty(N, d, **f32)
+            mp, rp = torch.empty(N, **f32), torch.empty(N, **f32)
+            ops.layernorm_fwd(h, st.view("post_layernorm.weight"), st.view("post_layernorm.bias"), pl, mp, rp, N, d,
+                              c.layer_norm_eps, in_mul=S)
+            if Tf > 1:
+                pooled = torch.empty(B, d, **f32)
+                ops.mean_rows(pl, pooled, B, Tf, d)
+            else:
+                pooled = pl
+            last = h.view(N, S, d)
+            s.pool = (h, mp, rp, None, None, None) if save else None
+        else:
+            last = torch.empty(rows, d, **f32)
+            mf, rf = torch.empty(rows, **f32), torch.empty(rows, **f32)
+            gw, gb = st.view("final_layer_norm.weight"), st.view("final_layer_norm.bias")
+            ops.layernorm_fwd(h, gw, gb, last, mf, rf, rows, d, c.layer_norm_eps)
+            eot = torch.empty(B, dtype=torch.int32, device=dev)
+            ops.argmax_rows(s.ids, eot, B, S)
+            pooled = torch.empty(B, d, **f32)
+            mp, rp = torch.empty(B, **f32), torch.empty(B, **f32)
+            ops.layernorm_fwd(h, gw, gb, pooled, mp, rp, B, d, c.layer_norm_eps, in_mul=S, in_off=eot)
+            last = last.view(B, S, d)
+            s.pool = (h, mp, rp, eot, mf, rf) if save else None
+        return s, last, pooled
+
+    # ------------------------------------------------------------------ backward implementation
+    def _linear_bwd(self, dy, x, wt, g_w, g_b, rows, dx_out=None, act=ops.ACT_NONE, aux_in=None):
+        """dW = dy^T x (fp32, written in place), db = colsum(dy), dx = dy W (through the transposed shadow)"""
+        T, dev = dy.dtype, dy.device
+        rp = _r64(rows)
+        n_out, k_in = dy.shape[1], x.shape[1]
+        dyt = torch.empty(n_out, rp, device=dev, dtype=T)
+        ops.transpose_pad(dy, dyt, colsum=g_b, R=rows)
+        xt = torch.empty(k_in, rp, device=dev, dtype=T)
+        ops.transpose_pad(x, xt, R=rows)
+        ops.gemm_nt(dyt, xt, g_w, K=rp)
+        if dx_out is not None:
+            ops.gemm_nt(dy, wt, dx_out, act=act, aux_in=aux_in, M=rows)
+        return dx_out
+
+    def _backward_impl(self, s, d_last, d_pooled):
+        c, st, T = self.config, self._store, self.compute_dtype
+        dev = st.master.device
+        d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
+        hd = d // H
+        B, Tf, N, S, rows = s.geom
+        st.zero_accumulated()
+        g = st.gview
+        f32 = dict(device=dev, dtype=torch.float32)
+        h_fin, mp, rp, eot, mf, rf = s.pool
+        if d_last is not None and c.kind == "vision":
+            dh = d_last.reshape(rows, d).to(torch.float32).clone()
+        else:
+            dh = torch.zeros(rows, d, **f32)
+        tail = "post_layernorm" if c.kind == "vision" else "final_layer_norm"
+        gw = st.view(f"{tail}.weight")
+        if d_pooled is not None:
+            dp = d_pooled.to(torch.float32).contiguous()
+            ops.layernorm_bwd(dp, h_fin, mp, rp, gw, dh, g(f"{tail}.weight"), g(f"{tail}.bias"), N if c.kind == "vision" else B, d,
+                              accumulate=True, dy_div=Tf if c.kind == "vision" else 1,
+                              dy_scale=1.0 / Tf if c.kind == "vision" else 1.0, in_mul=S, in_off=eot)
+        if d_last is not None and c.kind == "text":
+            dl = d_last.reshape(rows, d).to(torch.float32).contiguous()
+            ops.layernorm_bwd(dl, h_fin, mf, rf, gw, dh, g(f"{tail}.weight"), g(f"{tail}.bias"), rows, d, accumulate=True)
+        dh_T = torch.empty(rows, d, device=dev, dtype=T)
+        ops.cast_rows(dh, dh_T, rows, d)
+        dact = ops.ACT_GRAD[ops.ACT_CODE[c.hidden_act]]
+        for i in reversed(range(c.num_hidden_layers)):
+            L = self._lp[i]
+            pfx = f"encoder.layers.{i}"
+            rec = s.layers[i]
+            # ---- MLP block: h3 = h2 + fc2(act(fc1(LN2(h2))))
+            h2, x2, m2, r2, u, a = rec.m
+            du = torch.empty(rows, f, device=dev, dtype=T)
+            self._linear_bwd(dh_T, a, self._w(f"{pfx}.fc2")[1], L.g_fc2_w, L.g_fc2_b, rows, dx_out=du, act=dact, aux_in=u)
+            dx2 = torch.empty(rows, d, device=dev, dtype=T)
+            self._linear_bwd(du, x2, self._w(f"{pfx}.fc1")[1], L.g_fc1_w, L.g_fc1_b, rows, dx_out=dx2)
+            ops.layernorm_bwd(dx2, h2, m2, r2, L.ln2_w, dh, L.g_ln2_w, L.g_ln2_b, rows, d, accumulate=True, dx_cast=dh_T)
+            # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
+            hin, x1, m1, r1, qkv, ctx, lse = rec.a
+            dctx = torch.empty(rows, d, device=dev, dtype=T)
+            self._linear_bwd(dh_T, ctx, self._w(f"{pfx}.out")[1], L.g_out_w, L.g_out_b, rows, dx_out=dctx)
+            dqkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
+            ops.attention_bwd(qkv, dctx, lse, dqkv, N, S, H, hd, causal=s.causal, key_mask=s.key_mask)
+            dx1 = torch.empty(rows, d, device=dev, dtype=T)
+            self._linear_bwd(dqkv, x1, self._w(f"{pfx}.qkv")[1], L.g_qkv_w, L.g_qkv_b, rows, dx_out=dx1)
+            ops.layernorm_bwd(dx1, hin, m1, r1, L.ln1_w, dh, L.g_ln1_w, L.g_ln1_b, rows, d, accumulate=True, dx_cast=dh_T)
+            if c.add_time_attn:
+                hin, xt, mt, rt, qkv, ctx, lse = rec.t
+                dctx = torch.empty(rows, d, device=dev, dtype=T)
+                self._linear_bwd(dh_T, ctx, self._w(f"{pfx}.tout")[1], L.g_tout_w, L.g_tout_b, rows, dx_out=dctx)
+                dqkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
+                ops.attention_bwd(qkv, dctx, lse, dqkv, B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
+                dxt = torch.empty(rows, d, device=dev, dtype=T)
+                self._linear_bwd(dqkv, xt, self._w(f"{pfx}.tqkv")[1], L.g_tqkv_w, L.g_tqkv_b, rows, dx_out=dxt)
+                ops.layernorm_bwd(dxt, hin, mt, rt, L.tln_w, dh, L.g_tln_w, L.g_tln_b, rows, d, accumulate=True, dx_cast=dh_T)
+                if Tf != 1:
+                    ops.colsum(dh, L.g_temb, div=S, mod=Tf, R=rows)
+            s.layers[i] = None
+        # ---- embeddings
+        if c.kind == "vision":
+            U, x0, m0, r0 = s.emb
+            dx = torch.empty(rows, d, **f32)
+            ops.layernorm_bwd(dh, x0, m0, r0, st.view("pre_layrnorm.weight"), dx, g("pre_layrnorm.weight"), g("pre_layrnorm.bias"),
+                              rows, d, accumulate=False)
+            ops.colsum(dx, g("embeddings.position_embedding.weight"), div=1, mod=S, R=rows)
+            ops.colsum(dx.view(N, S * d)[:, :d], g("embeddings.class_embedding"), R=N)
+            P = S - 1
+            dpe = torch.empty(N * P, d, device=dev, dtype=T)
+            ops.cast_rows(dx, dpe, N * P, d, rdiv=P, roff=1)
+            b = self._mat_blocks["patch"]
+            gwp = st.block_view(b, st.grad).view(d, b.numel // d)
+            self._linear_bwd(dpe, U, None, gwp, None, N * P)
+        else:
+            ops.token_embed_bwd(s.ids, dh, g("embeddings.token_embedding.weight"), g("embeddings.position_embedding.weight"), B, S, d)
+
+    def attach_grads(self):
+        st = self._store
+        st.ensure_grad()
+        for name in self._param_names:
+            p = self.get_parameter(name)
+            if p.grad is None or p.grad.data_ptr() != st.gview(name).data_ptr():
+                p.grad = st.gview(name)
+
+
+class _TowerFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, anchor, tower: ClipTower, inputs, need_grad, *params):
+        state, last, pooled = tower._forward_impl(inputs, save=need_grad)
+        ctx.tower, ctx.state, ctx.nparams = tower, state, len(params)
+        return last, pooled
+
+    @staticmethod
+    def backward(ctx, d_last, d_pooled):
+        tower, state = ctx.tower, ctx.state
+        if state is None or not state.save:
+            raise RuntimeError("tower backward called twice or without saved activations")
+        ctx.state = None
+        tower._backward_impl(state, d_last, d_pooled)
+        if ctx.nparams:
+            st = tower._store
+            grads = tuple(st.gview(n).clone() for n in tower._param_names)
+            return (None, None, None, None) + grads
+        tower.attach_grads()
+        return (None, None, None, None)

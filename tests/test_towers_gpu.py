@@ -1,0 +1,225 @@
+"""Tower / bundle / fusion parity on the GPU: HIP path (through the drop-in modules and the C ABI) against
+(a) the fixtures captured from the reference and (b) the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-3 relative, fp32 instantiation.  The bf16 instantiation is checked at 3e-2."""
+import types
+
+import pytest
+import torch
+
+import missm_oracle as O
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-3
+TOLBF = 3e-2
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import missm_benchmark_amd as M
+    lb, base = M.install()
+    from missm_benchmark_amd import towers
+    return types.SimpleNamespace(lb=lb, base=base, towers=towers)
+
+
+def rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.isfinite(a).all()
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
+
+
+def make_tower(pkg, cfgd, kind, params, dtype):
+    fields = pkg.towers.TowerConfig.__dataclass_fields__
+    cfg = pkg.towers.TowerConfig(kind=kind, **{k: v for k, v in cfgd.items() if k in fields and k != "kind"})
+    t = pkg.towers.ClipTower(cfg, compute_dtype=dtype)
+    res = t.load_state_dict(params, strict=True)
+    return t.cuda()
+
+
+def vision_inputs(fix, cfg):
+    if "pixel_values" in fix:
+        return fix["pixel_values"]
+    shape = (fix["batch"], cfg.num_channels) + ((cfg.num_frames,) if cfg.num_frames > 1 else ()) + (cfg.image_size, cfg.image_size)
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(fix["seed_x"]))
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOLBF)])
+@pytest.mark.parametrize("name", ["vision_tiny", "video_tiny", "vision_s197"])
+def test_vision_tower_vs_reference_fixture(pkg, name, dtype, tol):
+    fix = load_golden(name)
+    ocfg = O.VisionCfg(**fix["cfg"])
+    params = fix.get("params") or O.init_tower_params(ocfg, fix["seed_w"])
+    tower = make_tower(pkg, fix["cfg"], "vision", params, dtype)
+    x = vision_inputs(fix, ocfg)
+    last, pooled = tower(x.cuda())
+    assert rel(pooled, fix["pooled"]) < tol
+    if "last_hidden_state" in fix:
+        assert rel(last, fix["last_hidden_state"]) < tol
+        cp, ch = fix["cot_pooled"], fix["cot_last"]
+    else:
+        assert rel(last[:, :4, :64], fix["last_hidden_slice"]) < tol
+        cp = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(fix["seed_x"] + 100))
+        ch = torch.randn(last.shape, generator=torch.Generator().manual_seed(fix["seed_x"] + 101)) * 0.1
+    ((pooled * cp.cuda()).sum() + (last * ch.cuda()).sum()).backward()
+    gtol = tol * (2 if dtype == torch.float32 else 3)
+    for k, g in fix["grads"].items():
+        mine = tower.get_parameter(k).grad
+        assert mine is not None, k
+        if mine.shape != g.shape:
+            mine = mine[:64, :64] if mine.dim() == 2 else mine[:64]
+        assert rel(mine, g) < gtol, k
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOLBF)])
+def test_text_tower_vs_fixture(pkg, dtype, tol):
+    fix = load_golden("text_tiny")
+    tower = make_tower(pkg, fix["cfg"], "text", fix["params"], dtype)
+    ids, mask = fix["input_ids"].cuda(), fix["attention_mask"].cuda()
+    last, pooled = tower(input_ids=ids, attention_mask=mask)
+    assert rel(pooled, fix["pooled"]) < tol
+    valid = fix["attention_mask"].bool()
+    assert rel(last.cpu()[valid], fix["last_hidden_state"][valid]) < tol
+    (pooled * fix["cot_pooled"].cuda()).sum().backward()
+    for k, g in fix["grads"].items():
+        assert rel(tower.get_parameter(k).grad, g) < tol * 3, k
+    with pytest.raises(ValueError, match="You have to specify input_ids"):
+        tower()
+
+
+def test_vision_errors_and_input_ranks(pkg):
+    fix = load_golden("video_tiny")
+    tower = make_tower(pkg, fix["cfg"], "vision", fix["params"], torch.float32)
+    with pytest.raises(ValueError, match="You have to specify pixel_values"):
+        tower(None)
+    x5 = fix["pixel_values"]                     # [B, C, T, H, W]
+    B, C, T, H, W = x5.shape
+    with torch.no_grad():
+        _, p5 = tower(x5.cuda())
+        x7 = x5.permute(0, 2, 1, 3, 4).reshape(B, 1, T, 1, C, H, W)   # (b, pair, T, bs, C, H, W) flattens to (b t) frames
+        _, p7 = tower(x7.cuda())
+    assert rel(p7, p5) < 1e-6
+    with pytest.raises(ValueError):
+        tower(x5[:, :, :2].cuda())               # wrong frame count for the time attention
+
+
+def test_state_dict_roundtrip_and_device_move(pkg):
+    fix = load_golden("vision_tiny")
+    tower = make_tower(pkg, fix["cfg"], "vision", fix["params"], torch.float32)
+    sd = tower.state_dict()
+    assert set(sd) == set(fix["params"])
+    for k, v in fix["params"].items():
+        assert torch.equal(sd[k].cpu(), v), k
+    # parameters stay views of one flat allocation after .cuda()
+    base = tower.flat_master()
+    assert all(p.data_ptr() >= base.data_ptr() and p.data_ptr() < base.data_ptr() + base.numel() * 4 for p in tower.parameters())
+    # an in-place parameter update (what an optimizer does) is picked up by the compute-dtype shadows
+    x = fix["pixel_values"].cuda()
+    with torch.no_grad():
+        _, p0 = tower(x)
+        tower.get_parameter("encoder.layers.0.mlp.fc1.weight").mul_(1.5)
+        _, p1 = tower(x)
+    assert rel(p1, p0) > 1e-4
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32)])
+def test_fusion_sum_and_bundle_vs_reference_fixture(pkg, dtype, tol):
+    fix = load_golden("fusion_sum")
+    mt = fix["modality_types"]
+    fd = fix["params"]["modal_proj." + mt[0] + ".weight"].shape
+    args = types.SimpleNamespace(modality_types=mt, feature_dims=fd[1], fusion_dim=fd[0], dropout_prob=0.0, fusion_type="sum")
+    C = fix["logits"].shape[1]
+    fusion = pkg.base.modal_sum(args, C)
+    fusion.load_state_dict(fix["params"], strict=True)
+    fusion = fusion.cuda()
+    emb = {m: e.cuda().requires_grad_(True) for m, e in fix["emb"].items()}
+    logits = fusion(emb, fix["missing_index"].cuda())
+    assert rel(logits, fix["logits"]) < 1e-5
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    loss = HipCrossEntropyLoss()(logits, fix["labels"].cuda())
+    assert abs(float(loss) - float(fix["loss"])) < 1e-5
+    loss.backward()
+    for m in mt:
+        assert rel(emb[m].grad, fix["emb_grads"][m]) < 1e-4, m
+    for k, g in fix["grads"].items():
+        assert rel(fusion.get_parameter(k).grad, g) < 1e-4, k
+    assert pkg.base.missing_type_index["language"] == 1 and pkg.base.missing_type_index["image"] == 4
+    # bundle: projection -> L2 normalise -> temperature (languagebind/__init__.py:78-84)
+    bf = load_golden("bundle")
+    from missm_benchmark_amd import nn as hnn
+    for m, ref in bf["out"].items():
+        w = bf["proj"][m].cuda()
+        e = hnn._LinearFn.apply(bf["pooled"][m].cuda(), w, None, False, None, 0)
+        scale = 1.0 if m == "language" else float(torch.tensor(bf["logit_scale"]).exp())
+        assert rel(hnn.l2norm_scale(e, scale), ref) < 1e-5
+
+
+def _tiny_model(pkg, dtype, seed=0):
+    T = pkg.towers.TowerConfig
+    tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16)
+    cfgs = {"video": T(kind="vision", add_time_attn=True, num_frames=4, **tiny), "image": T(kind="vision", **tiny)}
+    tcfg = T(kind="text", hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, vocab_size=512,
+             max_position_embeddings=16)
+    enc = pkg.lb.LanguageBind({"video": "LanguageBind_Video", "image": "LanguageBind_Image"}, configs=cfgs, text_config=tcfg,
+                              projection_dim=48, compute_dtype=dtype, seed=seed)
+    args = types.SimpleNamespace(modality_types=["language", "video", "image"], feature_dims=48, fusion_dim=32, dropout_prob=0.0,
+                                 fusion_type="sum")
+    return pkg.base.finetune_model(args, 5, enc), cfgs, tcfg, args
+
+
+def _oracle_of(model, cfgs, tcfg, args):
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    tp, tc = {}, {}
+    for m in ("video", "image", "language"):
+        pre = f"encoder.modality_encoder.{m}."
+        tp[m] = {k[len(pre):]: v.requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+    oc = lambda c: O.VisionCfg(**{k: getattr(c, k) for k in O.VisionCfg.__dataclass_fields__})
+    tc = {"video": oc(cfgs["video"]), "image": oc(cfgs["image"]),
+          "language": O.TextCfg(**{k: getattr(tcfg, k) for k in O.TextCfg.__dataclass_fields__})}
+    proj = {m: sd[f"encoder.modality_proj.{m}.weight"].requires_grad_(True) for m in tp}
+    scales = {m: torch.tensor(2.6592) for m in ("video", "image")}
+    fp = {k[len("fusion."):]: v.requires_grad_(True) for k, v in sd.items() if k.startswith("fusion.")}
+    return tp, tc, proj, scales, fp
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, 5e-2)])
+def test_finetune_model_end_to_end_vs_oracle(pkg, dtype, tol):
+    """finetune_model.forward + CE loss + full backward on 3 modalities (text, video with time attention, image)
+    with one missing-modality code per sample, against the CPU oracle."""
+    model, cfgs, tcfg, args = _tiny_model(pkg, dtype)
+    tp, tc, proj, scales, fp = _oracle_of(model, cfgs, tcfg, args)
+    model = model.cuda()
+    B = 6
+    g = torch.Generator().manual_seed(5)
+    ids, mask = O.synth_text_batch(B, 16, 3, vocab=512)
+    data = {"language": {"input_ids": ids, "attention_mask": mask},
+            "video": {"pixel_values": torch.randn(B, 3, 4, 32, 32, generator=g)},
+            "image": {"pixel_values": torch.randn(B, 3, 32, 32, generator=g)}}
+    missing = torch.tensor([0, 1, 2, 4, 0, 2])
+    labels = torch.randint(0, 5, (B,), generator=g)
+    ologits, oemb = O.finetune_forward(data, missing, tp, tc, proj, scales, fp, args.modality_types)
+    oloss = O.cross_entropy(ologits, labels)
+    oloss.backward()
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    gdata = {m: {k: v.cuda() for k, v in d.items()} for m, d in data.items()}
+    logits = model(gdata, missing.cuda())
+    loss = HipCrossEntropyLoss()(logits, labels.cuda())
+    loss.backward()
+    assert rel(logits, ologits) < tol
+    assert abs(float(loss) - float(oloss)) < tol * max(1.0, float(oloss))
+    checks = {"encoder.modality_encoder.video.encoder.layers.0.temporal_attn.q_proj.weight": tp["video"]["encoder.layers.0.temporal_attn.q_proj.weight"],
+              "encoder.modality_encoder.video.encoder.layers.1.mlp.fc1.weight": tp["video"]["encoder.layers.1.mlp.fc1.weight"],
+              "encoder.modality_encoder.video.embeddings.patch_embedding.weight": tp["video"]["embeddings.patch_embedding.weight"],
+              "encoder.modality_encoder.image.encoder.layers.0.self_attn.k_proj.bias": tp["image"]["encoder.layers.0.self_attn.k_proj.bias"],
+              "encoder.modality_encoder.image.pre_layrnorm.weight": tp["image"]["pre_layrnorm.weight"],
+              "encoder.modality_encoder.language.embeddings.token_embedding.weight": tp["language"]["embeddings.token_embedding.weight"],
+              "encoder.modality_encoder.language.encoder.layers.0.layer_norm1.weight": tp["language"]["encoder.layers.0.layer_norm1.weight"],
+              "encoder.modality_proj.video.weight": proj["video"], "fusion.modal_proj.image.weight": fp["modal_proj.image.weight"],
+              "fusion.head.head.3.bias": fp["head.head.3.bias"]}
+    gt = tol * (3 if dtype == torch.float32 else 4)
+    for k, ref in checks.items():
+        assert rel(model.get_parameter(k).grad, ref.grad) < gt, k
