@@ -68,10 +68,11 @@ int missm_layernorm_fwd(const float* x, float* x_wb, const float* add, int add_d
                         const float* gamma, const float* beta, void* y, float* mean, float* rstd, int rows, int cols, float eps,
                         int out_dtype, void* stream);
 /* dx (fp32, same row mapping as x; += when accumulate) ; dgamma/dbeta atomically accumulated (caller zeroes).
- * dy row = row / dy_div, scaled by dy_scale (mean over frames). */
+ * dy row = row / dy_div, scaled by dy_scale (mean over frames).  dx_cast (optional) receives the updated dx rows
+ * converted to dy's dtype: the GEMM operand of the next backward block. */
 int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
                         const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate, float* dgamma,
-                        float* dbeta, int rows, int cols, int dy_dtype, void* stream);
+                        float* dbeta, void* dx_cast, int rows, int cols, int dy_dtype, void* stream);
 /* out[b] = mean_t in[b*T + t]   (pooled_output.reshape(B, T, -1).mean(1), image/modeling_image.py:662). */
 int missm_mean_rows(const float* in, float* out, int B, int T, int cols, void* stream);
 
@@ -90,6 +91,9 @@ int missm_attention_bwd(const void* qkv, const void* dout, const float* lse, voi
  * A[n*P + p, c*ps*ps + ky*ps + kx] of type `dtype` (the conv weight's .view(d, -1) order). */
 int missm_unfold_patches(const float* pixels, void* out, int B, int T, int C, int H, int W, int ps, long stride_b,
                          long stride_t, long stride_c, int dtype, void* stream);
+/* out[r] = in[rdiv > 0 ? r + r / rdiv + roff : r] converted fp32 -> `dtype` (residual-gradient stream -> GEMM operand;
+ * rdiv = S-1, roff = 1 drops the CLS rows for the patch-embedding weight gradient). */
+int missm_cast_rows(const float* in, void* out, long R, int C, int rdiv, int roff, int dtype, void* stream);
 /* x[n, s, :] = (s == 0 ? cls : patches[n*(S-1) + s-1]) + pos[s]   (CLIPVisionEmbeddings, video/modeling_video.py:48-50). */
 int missm_embed_assemble(const void* patches, const float* cls, const float* pos, float* x, int N, int S, int d, int dtype,
                          void* stream);

@@ -19,7 +19,8 @@ SIGNATURES = {
     "missm_colsum": [P, P, I, I, I, I, I, I, P],
     "missm_cast_weight": [P, P, P, I, I, I, P],
     "missm_layernorm_fwd": [P, P, P, I, I, I, P, P, P, P, P, P, I, I, F, I, P],
-    "missm_layernorm_bwd": [P, I, F, P, I, P, P, P, P, P, I, P, P, I, I, I, P],
+    "missm_layernorm_bwd": [P, I, F, P, I, P, P, P, P, P, I, P, P, P, I, I, I, P],
+    "missm_cast_rows": [P, P, L, I, I, I, I, P],
     "missm_mean_rows": [P, P, I, I, I, P],
     "missm_attention_fwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, F, I, P],
     "missm_attention_bwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, F, I, P],

@@ -91,6 +91,7 @@ struct LnBwdArgs {
   int accumulate;
   float* dgamma; float* dbeta;  // fp32 [cols], atomically accumulated (caller zeroes)
   int rows, cols;
+  void* dx_cast;         // optional Tin copy of the updated dx rows (GEMM operand of the next backward block)
 };
 
 template <typename Tin, int CH>
@@ -146,6 +147,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[c][j] - s1 - xh[c][j] * s2);
         if (a.accumulate) { const f32x4 p = load4(dxr + col); o += p; }
         store4(dxr + col, o);
+        if (a.dx_cast) store4(static_cast<Tin*>(a.dx_cast) + irow * a.cols + col, o);
       }
     }
   }
@@ -209,10 +211,10 @@ extern "C" int missm_layernorm_fwd(const float* x, float* x_wb, const float* add
 
 extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
                                    const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate,
-                                   float* dgamma, float* dbeta, int rows, int cols, int dy_dtype, void* stream) {
+                                   float* dgamma, float* dbeta, void* dx_cast, int rows, int cols, int dy_dtype, void* stream) {
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd: cols must be a positive multiple of 4");
   LnBwdArgs a{dy, dy_div > 0 ? dy_div : 1, dy_scale, x, in_mul > 0 ? in_mul : 1, in_off, mean, rstd, gamma, dx, accumulate,
-              dgamma, dbeta, rows, cols};
+              dgamma, dbeta, rows, cols, dx_cast};
   int blocks = (rows + 3) / 4;
   if (blocks > 1024) blocks = 1024;
   dim3 grid(blocks), block(256);

@@ -75,6 +75,19 @@ __global__ void argmax_rows_kernel(const long* __restrict__ ids, int* __restrict
   out[b] = bi;
 }
 
+// fp32 rows -> T rows with an optional row gather: in_row = r + r / rdiv + roff  (rdiv > 0), else r
+template <typename T>
+__global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict__ in, T* __restrict__ out, long R, int C, int rdiv, int roff) {
+  const int q4 = C / 4;
+  const long total = R * q4;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int c = (idx % q4) * 4;
+    const long r = idx / q4;
+    const long ir = rdiv > 0 ? r + r / rdiv + roff : r;
+    store4(out + r * C + c, load4(in + ir * C + c));
+  }
+}
+
 // ---- small fp32 linears of the projection / fusion tail: one wavefront per output element ----
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int I, int O,
@@ -255,6 +268,14 @@ extern "C" int missm_unfold_patches(const float* pixels, void* out, int B, int T
   if (dtype == kBF16) hipLaunchKernelGGL(unfold_kernel<bf16>, grid, block, 0, S_(stream), pixels, (bf16*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c);
   else hipLaunchKernelGGL(unfold_kernel<float>, grid, block, 0, S_(stream), pixels, (float*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c);
   return missm_check_launch("unfold_patches");
+}
+
+extern "C" int missm_cast_rows(const float* in, void* out, long R, int C, int rdiv, int roff, int dtype, void* stream) {
+  MISSM_CHECK_ARG(R > 0 && C > 0 && C % 4 == 0, "cast_rows: bad shape");
+  dim3 grid(grid_for(R * (C / 4), 8192)), block(256);
+  if (dtype == kBF16) hipLaunchKernelGGL(cast_rows_kernel<bf16>, grid, block, 0, S_(stream), in, (bf16*)out, R, C, rdiv, roff);
+  else hipLaunchKernelGGL(cast_rows_kernel<float>, grid, block, 0, S_(stream), in, (float*)out, R, C, rdiv, roff);
+  return missm_check_launch("cast_rows");
 }
 
 extern "C" int missm_embed_assemble(const void* patches, const float* cls, const float* pos, float* x, int N, int S, int d, int dtype,

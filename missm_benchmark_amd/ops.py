@@ -101,10 +101,18 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, *, add=None, a
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, cols, *, accumulate=True, dy_div=1, dy_scale=1.0,
-                  in_mul=1, in_off=None):
+                  in_mul=1, in_off=None, dx_cast=None):
+    if dx_cast is not None and dx_cast.dtype != dy.dtype:
+        raise _lib.MissmError("layernorm_bwd: dx_cast must have dy's dtype")
     _lib.call("missm_layernorm_bwd", dy.data_ptr(), dy_div, float(dy_scale), x.data_ptr(), in_mul, _p(in_off), mean.data_ptr(),
-              rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), int(accumulate), _p(dgamma), _p(dbeta), rows, cols, dt(dy), _s())
+              rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), int(accumulate), _p(dgamma), _p(dbeta), _p(dx_cast), rows, cols,
+              dt(dy), _s())
     return dx
+
+
+def cast_rows(x, out, R, C, rdiv=0, roff=0):
+    _lib.call("missm_cast_rows", x.data_ptr(), out.data_ptr(), R, C, rdiv, roff, dt(out), _s())
+    return out
 
 
 def mean_rows(x, out, B, T, cols):

@@ -33,6 +33,14 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
 
 
+def grad_ok(name, mine, ref, tol, dtype):
+    """k_proj.bias has an identically-zero gradient (softmax is invariant to a per-query constant), so the reference
+    value is rounding noise: compare it on an absolute scale."""
+    if name.endswith("k_proj.bias"):
+        return float((mine.detach().float().cpu() - ref.detach().float().cpu()).abs().max()) < (1e-5 if dtype == torch.float32 else 5e-3)
+    return rel(mine, ref) < tol
+
+
 def make_tower(pkg, cfgd, kind, params, dtype):
     fields = pkg.towers.TowerConfig.__dataclass_fields__
     cfg = pkg.towers.TowerConfig(kind=kind, **{k: v for k, v in cfgd.items() if k in fields and k != "kind"})
@@ -72,7 +80,7 @@ def test_vision_tower_vs_reference_fixture(pkg, name, dtype, tol):
         assert mine is not None, k
         if mine.shape != g.shape:
             mine = mine[:64, :64] if mine.dim() == 2 else mine[:64]
-        assert rel(mine, g) < gtol, k
+        assert grad_ok(k, mine, g, gtol, dtype), k
 
 
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOLBF)])
@@ -86,7 +94,7 @@ def test_text_tower_vs_fixture(pkg, dtype, tol):
     assert rel(last.cpu()[valid], fix["last_hidden_state"][valid]) < tol
     (pooled * fix["cot_pooled"].cuda()).sum().backward()
     for k, g in fix["grads"].items():
-        assert rel(tower.get_parameter(k).grad, g) < tol * 3, k
+        assert grad_ok(k, tower.get_parameter(k).grad, g, tol * 3, dtype), k
     with pytest.raises(ValueError, match="You have to specify input_ids"):
         tower()
 
@@ -222,4 +230,4 @@ def test_finetune_model_end_to_end_vs_oracle(pkg, dtype, tol):
               "fusion.head.head.3.bias": fp["head.head.3.bias"]}
     gt = tol * (3 if dtype == torch.float32 else 4)
     for k, ref in checks.items():
-        assert rel(model.get_parameter(k).grad, ref.grad) < gt, k
+        assert grad_ok(k, model.get_parameter(k).grad, ref.grad, gt, dtype), k
