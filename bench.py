@@ -1,0 +1,183 @@
+#!/usr/bin/env python3
+"""Benchmark of the MissM-Benchmark hot path on MI355X: multimodal samples/s, fwd + bwd + all-reduce + Adam.
+
+    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
+           bench.py --gpus N --steps K --warmup W          (N > 1: one rank per GPU, RCCL)
+
+Workload (BASELINE.json configs[2], the config the metric is quoted on): 5 modalities (video T=8, image, audio, depth,
+thermal), synthetic N(0,1) pixels, B = 32 per GPU, ViT-B/16 towers (d=768, L=12, 197 tokens), `sum` fusion, C = 8
+classes, random-init weights, bf16 GEMM/attention operands with fp32 accumulation, residual stream, master weights and
+Adam.  A step = forward, cross-entropy, full backward through all five towers, gradient all-reduce (N > 1), fused Adam
+on every parameter that received a gradient.  Weak scaling: per-GPU batch fixed.
+
+The JSON line also carries
+  roofline     : the dominant kernel (bf16 MFMA GEMM): algorithmic FLOPs of every launch in the timed region / their
+                 summed durations from HIP events recorded on the launching stream, against the 2.5 PFLOP/s dense bf16 peak
+  cpu_baseline : the CPU oracle (the validated restatement of the reference) timed on this box's host cores on a bounded
+                 sample of the same workload (rank 0, N = 1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+import types
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODALITIES = ["image", "audio", "depth", "thermal", "video"]   # video last in forward => first in backward (largest all-reduce overlaps the rest)
+PEAK_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="samples per GPU")
+    ap.add_argument("--missing", type=float, default=0.0, help="missing-modality ratio (configs[3] uses 0.3)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--modalities", default=",".join(MODALITIES))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    return ap.parse_args()
+
+
+def cpu_baseline(modalities, cpu_batch):
+    """Time the CPU oracle (oracle/missm_oracle.py) on a bounded sample: fwd + bwd of `cpu_batch` 5-modality samples."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import missm_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfgs, params, proj, scales = {}, {}, {}, {}
+    for i, m in enumerate(modalities):
+        cfgs[m] = O.VisionCfg(add_time_attn=(m == "video"), num_frames=8 if m == "video" else 1)
+        params[m] = {k: v.requires_grad_(True) for k, v in O.init_tower_params(cfgs[m], seed=i).items()}
+        proj[m] = (torch.randn(768, 768, generator=torch.Generator().manual_seed(100 + i)) * 768 ** -0.5).requires_grad_(True)
+        scales[m] = torch.tensor(2.6592)
+    fp = {k: v.requires_grad_(True) for k, v in O.init_fusion_params(modalities, 768, 256, 8, seed=7).items()}
+    g = torch.Generator().manual_seed(1)
+    data = {m: {"pixel_values": torch.randn(*((cpu_batch, 3, 8, 224, 224) if m == "video" else (cpu_batch, 3, 224, 224)), generator=g)}
+            for m in modalities}
+    missing = torch.zeros(cpu_batch, dtype=torch.int64)
+    labels = torch.randint(0, 8, (cpu_batch,), generator=g)
+
+    def one():
+        logits, _ = O.finetune_forward(data, missing, params, cfgs, proj, scales, fp, modalities)
+        O.cross_entropy(logits, labels).backward()
+
+    one()  # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    one()
+    dt = time.perf_counter() - t0
+    return {"value": cpu_batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": f"{cpu_batch} sample(s) x {len(modalities)} modalities, fwd+bwd (no optimizer), fp32 torch CPU oracle, "
+                      f"1 timed pass after 1 warm-up ({dt:.1f} s)"}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU product path)"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", init_method="env://")
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import missm_benchmark_amd as M
+    from missm_benchmark_amd import ops
+    from missm_benchmark_amd.engine import TrainEngine
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    lb, base = M.install()
+    modalities = args.modalities.split(",")
+    cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    clip_type = {m: f"LanguageBind_{m.capitalize()}" for m in modalities}
+    enc = lb.LanguageBind(clip_type, compute_dtype=cdt, seed=0)
+    margs = types.SimpleNamespace(modality_types=modalities, feature_dims=768, fusion_dim=256, dropout_prob=0.1, fusion_type="sum")
+    model = base.finetune_model(margs, 8, enc).cuda()
+    model.train()
+    engine = TrainEngine(model, lr=1e-4)
+    criterion = HipCrossEntropyLoss()
+    B = args.batch
+    g = torch.Generator().manual_seed(1 + rank)
+    data = {}
+    for m in modalities:
+        shape = (B, 3, 8, 224, 224) if m == "video" else (B, 3, 224, 224)
+        data[m] = {"pixel_values": torch.randn(*shape, generator=g).cuda()}
+    labels = torch.randint(0, 8, (B,), generator=g).cuda()
+    if args.missing > 0:
+        from missm_benchmark_amd.data import synth_missing_index
+        missing = synth_missing_index(B, modalities, args.missing, 2025 + rank).cuda()
+    else:
+        missing = torch.zeros(B, dtype=torch.int64, device="cuda")
+
+    def step():
+        engine.zero_grad()
+        logits = model(data, missing)
+        loss = criterion(logits, labels)
+        loss.backward()
+        engine.step()
+        return loss
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    prof = None if args.no_roofline else []
+    ops.GEMM_PROFILE = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    ops.GEMM_PROFILE = None
+    tmax = torch.tensor([dt], device="cuda")
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax)
+    final_loss = float(loss)
+
+    roof = None
+    if prof:
+        flops = sum(f for _, _, f in prof)
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        ach = flops / (ms * 1e-3) / 1e12
+        roof = {"kernel": "gemm_nt_kernel<bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<float>", "bound": "mfma",
+                "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
+                "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
+                "launches": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),
+                "gemm_share_of_step": round(ms * 1e-3 / dt, 3)}
+    if rank == 0:
+        out = {"metric": "multimodal samples/sec (fwd+bwd) at B=32, 5 modalities", "value": round(B * world * args.steps / dt, 2),
+               "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "configs[2]: 5-modality (video T=8/image/audio/depth/thermal) ViT-B/16 towers + sum fusion, "
+                                      "fwd+bwd+allreduce+Adam", "per_gpu_batch": B, "global_batch": B * world,
+                          "modalities": modalities, "missing_ratio": args.missing, "params": engine.num_parameters(),
+                          "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
+               "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(modalities, args.cpu_batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -44,6 +44,9 @@ def _req(t: torch.Tensor, name: str):
         raise _lib.MissmError(f"{name}: innermost dimension must be contiguous")
 
 
+GEMM_PROFILE = None  # bench.py sets this to a list: (start_event, end_event, flops) per launch
+
+
 def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, bias=None, resid=None, aux_in=None, aux_out=None,
             act: int = ACT_NONE, alpha: float = 1.0, accumulate: bool = False, M=None, N=None, K=None):
     """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+bias) -> act (+resid). a/b share a dtype; out is that dtype or fp32."""
@@ -64,8 +67,15 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, bias=None, r
         raise _lib.MissmError("gemm: aux dtype must match the operands")
     if resid is not None and (resid.dtype != torch.float32 or resid.stride(0) != out.stride(0)):
         raise _lib.MissmError("gemm: resid must be fp32 with the output's leading dimension")
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("missm_gemm_nt", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
               float(alpha), _p(bias), _p(resid), _p(aux_in), _p(aux_out), ldaux, act, out_f32, int(accumulate), dt(a), _s())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K))
     return out
 
 

@@ -122,6 +122,8 @@ class ClipTower(nn.Module):
         self._shadow = {}
         self._shadow_version = None
         self._lp = None
+        self._grad_fresh = False     # True between a backward of this tower and the optimizer step that consumes it
+        self._post_backward = None   # set by engine.TrainEngine: called once the last backward kernel is enqueued
         self.reset_parameters(0 if seed is None else seed)
 
     # ------------------------------------------------------------------ parameters
@@ -521,6 +523,9 @@ class _TowerFn(torch.autograd.Function):
             raise RuntimeError("tower backward called twice or without saved activations")
         ctx.state = None
         tower._backward_impl(state, d_last, d_pooled)
+        tower._grad_fresh = True
+        if tower._post_backward is not None:
+            tower._post_backward(tower)
         if ctx.nparams:
             st = tower._store
             grads = tuple(st.gview(n).clone() for n in tower._param_names)
