@@ -16,7 +16,7 @@
 
 namespace missm {
 
-constexpr int BM = 128, BN = 128, RB = 128;  // tile rows / cols / bytes per LDS row
+constexpr int BM = 128, BN = 128, RB = 128;  // tile rows / cols / bytes per LDS row (k-contiguous operands)
 constexpr int GEMM_THREADS = 256;
 
 struct GemmArgs {
@@ -33,70 +33,127 @@ struct GemmArgs {
   int accumulate;         // out_f32 only: C += result
   int tiles_m, tiles_n;
   int vec_ok;             // ldc/ldaux/pointers allow 16-byte (fp32) / 8-byte (bf16) vector epilogue accesses
+  int splitk, k_per_split;  // splitk > 1: each K slice atomically adds its partial into the (zeroed) fp32 C
 };
 
-template <typename T>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmArgs g) {
+// swizzle key of a k-major ("transposed") tile row: the 8 rows touched by one half-wave of a transposed fragment read
+// ({8g+q} and {8g+8+q}, q = 0..3) get 8 distinct keys -> 8 distinct 32-byte slots of the 256-byte bank row.
+__device__ __forceinline__ int tkey(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
+template <int RBT> __device__ __forceinline__ int tswz(int row, int chunk16) { return row * RBT + ((chunk16 ^ (tkey(row) << 1)) << 4); }
+
+// fragment (one MFMA step) of a k-major tile [BK rows of k][128 columns]: lane (i, g) gets column c0 + i, its KPL k values
+template <typename T> struct KMajorFrag;
+template <> struct KMajorFrag<bf16> {
+  static constexpr int RBT = 256;
+  __device__ static __forceinline__ bf16x8 load(const char* lds, int ks, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+    const int r1 = ks * 32 + 8 * g + q, col = c0 + 4 * p;
+    const char* a0 = lds + tswz<RBT>(r1, col >> 3) + ((col & 7) << 1);
+    const char* a1 = lds + tswz<RBT>(r1 + 4, col >> 3) + ((col & 7) << 1);
+    i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(a0));
+    i16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(a1));
+    using i16x8 = __attribute__((ext_vector_type(8))) short;
+    i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+template <> struct KMajorFrag<float> {
+  static constexpr int RBT = 512;
+  __device__ static __forceinline__ f32x4 load(const char* lds, int ks, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4, col = c0 + i;
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float*>(lds + tswz<RBT>(ks * 16 + 4 * g + j, col >> 2) + ((col & 3) << 2));
+    return v;
+  }
+};
+
+// TA: A is stored [K, M] (reduction index on rows); TB: B is stored [K, N].  TA = TB = false is the NT form.
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
-  constexpr int BK = RB / sizeof(T);      // k elements per tile
+  constexpr int BK = RB / sizeof(T);      // k elements per tile (64 bf16 / 32 f32)
   constexpr int KSTEPS = BK / M_::KS;     // 2
-  __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * RB];
-  char* ldsA = lds;                       // [2][BM][RB]
-  char* ldsB = lds + 2 * BM * RB;         // [2][BN][RB]
+  constexpr int RBT = KMajorFrag<T>::RBT; // bytes per row of a k-major tile (128 elements)
+  constexpr int NCT = RBT / 16;           // 16-byte chunks per k-major row
+  constexpr int TILE_BYTES = BM * RB;     // 16 KiB either layout
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+  char* ldsA = lds;                       // [2][TILE_BYTES]
+  char* ldsB = lds + 2 * TILE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
   const int wm = wave >> 1, wn = wave & 1;
 
   const int ntiles = g.tiles_m * g.tiles_n;
-  const int logical = xcd_remap(blockIdx.x, ntiles);
+  const int bid = blockIdx.x;
+  const int split = bid / ntiles;
+  const int logical = xcd_remap(bid - split * ntiles, ntiles);
   const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
 
   const T* __restrict__ A = static_cast<const T*>(g.A);
   const T* __restrict__ B = static_cast<const T*>(g.B);
 
-  // staging assignment: 4 chunks of A and 4 of B per thread per K tile
-  const int s_chunk = tid & 7;
-  int a_row[4], b_row[4], b_lrow[4];
+  // ---- staging: 4 x 16-byte chunks of A and of B per thread per K tile ----
+  int a_lds[4], b_lds[4];
   const T* a_ptr[4];
   const T* b_ptr[4];
+  bool a_ok[4], b_ok[4];
+  int a_kofs[4], b_kofs[4];   // k offset (inside the tile) this chunk covers, for the K-edge predicate
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
-    const int r = (tid >> 3) + 32 * i;
-    a_row[i] = r;
-    int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
-    a_ptr[i] = A + (size_t)gr * g.lda + s_chunk * EPC;
-    // B tile row r (output column n0 + r) goes to LDS row pi(r) = 64*(r/64) + 16*(r%4) + (r%64)/4
-    b_row[i] = r;
-    b_lrow[i] = (r & 64) + ((r & 3) << 4) + ((r & 63) >> 2);
-    int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
-    b_ptr[i] = B + (size_t)gn * g.ldb + s_chunk * EPC;
+    if constexpr (!TA) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7;
+      int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
+      a_ptr[i] = A + (size_t)gr * g.lda + c * EPC;
+      a_lds[i] = swz<RB>(r, c * 16);
+      a_ok[i] = true; a_kofs[i] = c * EPC;
+    } else {
+      const int idx = tid + 256 * i, r = idx / NCT, c = idx % NCT;
+      a_ptr[i] = A + (size_t)r * g.lda + m0 + c * EPC;
+      a_lds[i] = tswz<RBT>(r, c);
+      a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = r;
+    }
+    if constexpr (!TB) {
+      const int r = (tid >> 3) + 32 * i, c = tid & 7;
+      // B tile row r (output column n0 + r) goes to LDS row pi(r) = 64*(r/64) + 16*(r%4) + (r%64)/4
+      const int lr = (r & 64) + ((r & 3) << 4) + ((r & 63) >> 2);
+      int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
+      b_ptr[i] = B + (size_t)gn * g.ldb + c * EPC;
+      b_lds[i] = swz<RB>(lr, c * 16);
+      b_ok[i] = true; b_kofs[i] = c * EPC;
+    } else {
+      const int idx = tid + 256 * i, r = idx / NCT, c = idx % NCT;
+      b_ptr[i] = B + (size_t)r * g.ldb + n0 + c * EPC;
+      b_lds[i] = tswz<RBT>(r, c);
+      b_ok[i] = (n0 + c * EPC) < g.N; b_kofs[i] = r;
+    }
   }
 
   u32x4 ra[4], rb[4];
   auto gload = [&](int k0) {
-    const bool kin = (k0 + s_chunk * EPC) < g.K;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      if (kin) {
-        ra[i] = *reinterpret_cast<const u32x4*>(a_ptr[i] + k0);
-        rb[i] = *reinterpret_cast<const u32x4*>(b_ptr[i] + k0);
-      } else {
-        ra[i] = u32x4{0, 0, 0, 0};
-        rb[i] = u32x4{0, 0, 0, 0};
-      }
+      const bool ain = a_ok[i] && (k0 + a_kofs[i]) < kend;
+      const bool bin = b_ok[i] && (k0 + b_kofs[i]) < kend;
+      ra[i] = u32x4{0, 0, 0, 0};
+      rb[i] = u32x4{0, 0, 0, 0};
+      if (ain) ra[i] = *reinterpret_cast<const u32x4*>(TA ? a_ptr[i] + (size_t)k0 * g.lda : a_ptr[i] + k0);
+      if (bin) rb[i] = *reinterpret_cast<const u32x4*>(TB ? b_ptr[i] + (size_t)k0 * g.ldb : b_ptr[i] + k0);
     }
   };
   auto lstore = [&](int buf) {
-    char* la = ldsA + buf * BM * RB;
-    char* lb = ldsB + buf * BN * RB;
+    char* la = ldsA + buf * TILE_BYTES;
+    char* lb = ldsB + buf * TILE_BYTES;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(la + swz<RB>(a_row[i], s_chunk * 16)) = ra[i];
-      *reinterpret_cast<u32x4*>(lb + swz<RB>(b_lrow[i], s_chunk * 16)) = rb[i];
+      *reinterpret_cast<u32x4*>(la + a_lds[i]) = ra[i];
+      *reinterpret_cast<u32x4*>(lb + b_lds[i]) = rb[i];
     }
   };
 
@@ -106,24 +163,31 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  const int nk = (g.K + BK - 1) / BK;
-  gload(0);
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  gload(kbeg);
   lstore(0);
   __syncthreads();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) gload((kt + 1) * BK);   // next tile's loads fly under this tile's MFMAs
-    const char* la = ldsA + buf * BM * RB;
-    const char* lb = ldsB + buf * BN * RB;
+    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);   // next tile's loads fly under this tile's MFMAs
+    const char* la = ldsA + buf * TILE_BYTES;
+    const char* lb = ldsB + buf * TILE_BYTES;
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       Frag fa[4], fb[4];
       const int cbyte = (ks * 4 + lg) * 16;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (!TA) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
+        else fa[i] = KMajorFrag<T>::load(la, ks, wm * 64 + i * 16, lane);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; ++j) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (!TB) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
+        else fb[j] = KMajorFrag<T>::load(lb, ks, wn * 64 + j * 16, lane);
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -133,69 +197,91 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_nt_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // ---- epilogue: lane owns rows (4*lg + r) of each 16-row tile i and columns 4*li + j (j = 0..3) ----
-  const int col = n0 + wn * 64 + li * 4;
-  if (col >= g.N) return;
-  const bool full4 = (col + 3 < g.N) && g.vec_ok;
-  f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-  if (g.bias) {
-    if (col + 3 < g.N) bias4 = load4(g.bias + col);
-    else
-      for (int j = 0; j < 4; ++j) if (col + j < g.N) bias4[j] = g.bias[col + j];
-  }
+  // ---- epilogue ----
+  // !TB: lane owns rows 4*lg + r of each 16-row tile i and the 4 CONSECUTIVE columns 4*li + j  (vector accesses)
+  //  TB: lane owns column 16*j + li of each n-tile j                                          (scalar accesses)
+  const bool first_split = split == 0;
+  auto finish = [&](float x, size_t off, size_t aoff) -> void {   // scalar tail of the epilogue for one element
+    if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
+      if (g.aux_out) static_cast<T*>(g.aux_out)[aoff] = from_f32<T>(x);
+      x = (g.act == MISSM_ACT_QGELU) ? quick_gelu(x) : gelu_erf(x);
+    } else if (g.act == MISSM_ACT_DQGELU || g.act == MISSM_ACT_DGELU) {
+      const float u = to_f32(static_cast<const T*>(g.aux_in)[aoff]);
+      x *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u) : gelu_erf_grad(u);
+    } else if (g.act == MISSM_ACT_RELU) {
+      x = fmaxf(x, 0.f);
+    }
+    if (g.out_f32) {
+      float* c = static_cast<float*>(g.C) + off;
+      if (g.splitk > 1) { atomicAdd(c, x); return; }
+      if (g.resid) x += g.resid[off];
+      if (g.accumulate) x += *c;
+      *c = x;
+    } else {
+      static_cast<T*>(g.C)[off] = from_f32<T>(x);
+    }
+  };
+
+  if constexpr (TB) {
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+    for (int j = 0; j < 4; ++j) {
+      const int col = n0 + wn * 64 + j * 16 + li;
+      if (col >= g.N) continue;
+      const float bv = (g.bias && first_split) ? g.bias[col] : 0.f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
-      if (row >= g.M) continue;
-      f32x4 v;
+      for (int i = 0; i < 4; ++i)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = acc[i][j][r] * g.alpha + bias4[j];
-      const size_t off = (size_t)row * g.ldc + col;
-      const size_t aoff = (size_t)row * g.ldaux + col;
-      if (full4) {
-        if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
-          if (g.aux_out) store4(static_cast<T*>(g.aux_out) + aoff, v);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = (g.act == MISSM_ACT_QGELU) ? quick_gelu(v[j]) : gelu_erf(v[j]);
-        } else if (g.act == MISSM_ACT_DQGELU || g.act == MISSM_ACT_DGELU) {
-          f32x4 u = load4(static_cast<const T*>(g.aux_in) + aoff);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u[j]) : gelu_erf_grad(u[j]);
-        } else if (g.act == MISSM_ACT_RELU) {
-#pragma unroll
-          for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+        for (int r = 0; r < 4; ++r) {
+          const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+          if (row < g.M) finish(acc[i][j][r] * g.alpha + bv, (size_t)row * g.ldc + col, (size_t)row * g.ldaux + col);
         }
-        if (g.out_f32) {
-          float* c = static_cast<float*>(g.C) + off;
-          if (g.resid) { f32x4 q = load4(g.resid + off); v += q; }
-          if (g.accumulate) { f32x4 q = load4(c); v += q; }
-          store4(c, v);
-        } else {
-          store4(static_cast<T*>(g.C) + off, v);
-        }
-      } else {  // ragged N edge: scalar path
-        for (int j = 0; j < 4; ++j) {
-          if (col + j >= g.N) break;
-          float x = v[j];
+    }
+    return;
+  } else {
+    const int col = n0 + wn * 64 + li * 4;
+    if (col >= g.N) return;
+    const bool full4 = (col + 3 < g.N) && g.vec_ok && g.splitk == 1;
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (g.bias && first_split) {
+      if (col + 3 < g.N) bias4 = load4(g.bias + col);
+      else
+        for (int j = 0; j < 4; ++j) if (col + j < g.N) bias4[j] = g.bias[col + j];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+        if (row >= g.M) continue;
+        f32x4 v;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = acc[i][j][r] * g.alpha + bias4[j];
+        const size_t off = (size_t)row * g.ldc + col;
+        const size_t aoff = (size_t)row * g.ldaux + col;
+        if (full4) {
           if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
-            if (g.aux_out) static_cast<T*>(g.aux_out)[aoff + j] = from_f32<T>(x);
-            x = (g.act == MISSM_ACT_QGELU) ? quick_gelu(x) : gelu_erf(x);
+            if (g.aux_out) store4(static_cast<T*>(g.aux_out) + aoff, v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (g.act == MISSM_ACT_QGELU) ? quick_gelu(v[j]) : gelu_erf(v[j]);
           } else if (g.act == MISSM_ACT_DQGELU || g.act == MISSM_ACT_DGELU) {
-            float u = to_f32(static_cast<const T*>(g.aux_in)[aoff + j]);
-            x *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u) : gelu_erf_grad(u);
+            f32x4 u = load4(static_cast<const T*>(g.aux_in) + aoff);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u[j]) : gelu_erf_grad(u[j]);
           } else if (g.act == MISSM_ACT_RELU) {
-            x = fmaxf(x, 0.f);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
           }
           if (g.out_f32) {
-            float* c = static_cast<float*>(g.C) + off + j;
-            if (g.resid) x += g.resid[off + j];
-            if (g.accumulate) x += *c;
-            *c = x;
+            float* c = static_cast<float*>(g.C) + off;
+            if (g.resid) { f32x4 q = load4(g.resid + off); v += q; }
+            if (g.accumulate) { f32x4 q = load4(c); v += q; }
+            store4(c, v);
           } else {
-            static_cast<T*>(g.C)[off + j] = from_f32<T>(x);
+            store4(static_cast<T*>(g.C) + off, v);
           }
+        } else {
+          for (int j = 0; j < 4; ++j)
+            if (col + j < g.N) finish(v[j], off + j, aoff + j);
         }
       }
     }
@@ -285,13 +371,16 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 
 using namespace missm;
 
-extern "C" int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, float alpha,
-                             const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act,
-                             int out_f32, int accumulate, int dtype, void* stream) {
+extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                          int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
+                          int ldaux, int act, int out_f32, int accumulate, int splitk, int dtype, void* stream) {
   MISSM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
-  const int epc = dtype == kBF16 ? 8 : 4;
   MISSM_CHECK_ARG(dtype == kBF16 || dtype == kF32, "gemm: dtype must be 0 (f32) or 1 (bf16)");
-  MISSM_CHECK_ARG(K % epc == 0 && lda % epc == 0 && ldb % epc == 0, "gemm: K, lda, ldb must be multiples of 16 bytes");
+  const int epc = dtype == kBF16 ? 8 : 4;
+  MISSM_CHECK_ARG(lda % epc == 0 && ldb % epc == 0, "gemm: lda, ldb must be multiples of 16 bytes");
+  MISSM_CHECK_ARG(trans_a ? (M % epc == 0) : (K % epc == 0), "gemm: the contiguous extent of A must be a multiple of 16 bytes");
+  MISSM_CHECK_ARG(trans_b ? (N % epc == 0) : (K % epc == 0), "gemm: the contiguous extent of B must be a multiple of 16 bytes");
+  MISSM_CHECK_ARG(!(trans_a && !trans_b), "gemm: A^T with k-contiguous B is not instantiated");
   MISSM_CHECK_ARG(!(resid && !out_f32) && !(accumulate && !out_f32), "gemm: resid/accumulate need out_f32");
   MISSM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "gemm: unaligned operand");
   MISSM_CHECK_ARG(!bias || ((uintptr_t)bias % 16 == 0), "gemm: bias must be 16-byte aligned");
@@ -302,11 +391,44 @@ extern "C" int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
              ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
-  dim3 grid(g.tiles_m * g.tiles_n), block(GEMM_THREADS);
+  const int bk = dtype == kBF16 ? 64 : 32;
+  const int tiles = g.tiles_m * g.tiles_n;
+  if (splitk <= 0) {  // auto: only worth it when the tile grid cannot fill the 256 CUs at 2 workgroups each
+    splitk = 1;
+    if (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE && tiles < 256) {
+      splitk = 512 / tiles;
+      const int maxs = K / (8 * bk);
+      if (splitk > maxs) splitk = maxs;
+      if (splitk < 1) splitk = 1;
+    }
+  }
+  MISSM_CHECK_ARG(splitk == 1 || (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE),
+                  "gemm: split-K needs a zero-initialised fp32 output and no epilogue");
+  int kps = (K + splitk - 1) / splitk;
+  kps = (kps + bk - 1) / bk * bk;
+  splitk = (K + kps - 1) / kps;
+  g.splitk = splitk; g.k_per_split = kps;
+  dim3 grid(tiles * splitk), block(GEMM_THREADS);
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (dtype == kBF16) hipLaunchKernelGGL(gemm_nt_kernel<bf16>, grid, block, 0, s, g);
-  else hipLaunchKernelGGL(gemm_nt_kernel<float>, grid, block, 0, s, g);
-  return missm_check_launch("gemm_nt");
+#define MISSM_GEMM_LAUNCH(T, TA, TB) hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, block, 0, s, g)
+  if (dtype == kBF16) {
+    if (!trans_a && !trans_b) MISSM_GEMM_LAUNCH(bf16, false, false);
+    else if (!trans_a && trans_b) MISSM_GEMM_LAUNCH(bf16, false, true);
+    else MISSM_GEMM_LAUNCH(bf16, true, true);
+  } else {
+    if (!trans_a && !trans_b) MISSM_GEMM_LAUNCH(float, false, false);
+    else if (!trans_a && trans_b) MISSM_GEMM_LAUNCH(float, false, true);
+    else MISSM_GEMM_LAUNCH(float, true, true);
+  }
+#undef MISSM_GEMM_LAUNCH
+  return missm_check_launch("gemm");
+}
+
+extern "C" int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, float alpha,
+                             const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act,
+                             int out_f32, int accumulate, int dtype, void* stream) {
+  return missm_gemm(A, B, C, M, N, K, lda, ldb, ldc, 0, 0, alpha, bias, resid, aux_in, aux_out, ldaux, act, out_f32, accumulate, 1,
+                    dtype, stream);
 }
 
 extern "C" int missm_transpose_pad(const void* in, void* out, int R, int C, int ld, int ldo, float* colsum, int dtype,

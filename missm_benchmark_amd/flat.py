@@ -69,10 +69,9 @@ class FlatStore:
         return self.grad
 
     def zero_accumulated(self):
-        """clear the range whose gradients are accumulated with atomics (everything after the GEMM weights)"""
-        g = self.ensure_grad()
-        if self.vec_start < self.total:
-            g[self.vec_start:].zero_()
+        """clear the gradient buffer: biases / LayerNorm / embedding gradients are accumulated with atomics, and so are
+        the split-K partial products of the weight gradients"""
+        self.ensure_grad().zero_()
 
     def move(self, fn):
         new = fn(self.master)

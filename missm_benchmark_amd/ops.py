@@ -47,20 +47,25 @@ def _req(t: torch.Tensor, name: str):
 GEMM_PROFILE = None  # bench.py sets this to a list: (start_event, end_event, flops) per launch
 
 
-def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, bias=None, resid=None, aux_in=None, aux_out=None,
-            act: int = ACT_NONE, alpha: float = 1.0, accumulate: bool = False, M=None, N=None, K=None):
-    """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+bias) -> act (+resid). a/b share a dtype; out is that dtype or fp32."""
+def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, bias=None,
+         resid=None, aux_in=None, aux_out=None, act: int = ACT_NONE, alpha: float = 1.0, accumulate: bool = False,
+         splitk: int = 1, M=None, N=None, K=None):
+    """out[M,N] = alpha * op(a) @ op(b) (+bias) -> act (+resid).
+    a is [M,K] (or [K,M] with trans_a); b is [N,K] (or [K,N] with trans_b); out is the operand dtype or fp32.
+    splitk: 1 off, 0 auto, >1 slices (needs a zeroed fp32 ``out``)."""
     _req(a, "gemm a"); _req(b, "gemm b"); _req(out, "gemm out")
-    M = a.shape[0] if M is None else M
-    N = b.shape[0] if N is None else N
-    K = a.shape[1] if K is None else K
     if a.dtype != b.dtype:
         raise _lib.MissmError("gemm: operand dtypes differ")
-    if K > a.shape[1] or K > b.shape[1] or M > a.shape[0] or N > b.shape[0] or out.shape[0] < M or out.shape[1] < N:
+    am, ak = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    bn, bk = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    M = am if M is None else M
+    N = bn if N is None else N
+    K = ak if K is None else K
+    if K > ak or K > bk or M > am or N > bn or out.shape[0] < M or out.shape[1] < N:
         raise _lib.MissmError(f"gemm: shapes a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)} vs M{M} N{N} K{K}")
     out_f32 = int(out.dtype == torch.float32)
-    if not out_f32 and (out.dtype != a.dtype or resid is not None or accumulate):
-        raise _lib.MissmError("gemm: output must be fp32 (required for resid/accumulate) or the operand dtype")
+    if not out_f32 and (out.dtype != a.dtype or resid is not None or accumulate or splitk != 1):
+        raise _lib.MissmError("gemm: output must be fp32 (required for resid/accumulate/split-K) or the operand dtype")
     aux = aux_in if aux_in is not None else aux_out
     ldaux = aux.stride(0) if aux is not None else out.stride(0)
     if aux is not None and aux.dtype != a.dtype:
@@ -71,12 +76,18 @@ def gemm_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, bias=None, r
     if prof is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    _lib.call("missm_gemm_nt", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
-              float(alpha), _p(bias), _p(resid), _p(aux_in), _p(aux_out), ldaux, act, out_f32, int(accumulate), dt(a), _s())
+    _lib.call("missm_gemm", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
+              int(trans_a), int(trans_b), float(alpha), _p(bias), _p(resid), _p(aux_in), _p(aux_out), ldaux, act, out_f32,
+              int(accumulate), int(splitk), dt(a), _s())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K))
     return out
+
+
+def gemm_nt(a, b, out, **kw):
+    """out[M,N] = a[M,K] @ b[N,K]^T ... (the forward-linear form; see gemm)."""
+    return gemm(a, b, out, trans_a=False, trans_b=False, **kw)
 
 
 def transpose_pad(x: torch.Tensor, out: torch.Tensor, colsum: Optional[torch.Tensor] = None, R=None, C=None):

@@ -411,17 +411,13 @@ class ClipTower(nn.Module):
 
     # ------------------------------------------------------------------ backward implementation
     def _linear_bwd(self, dy, x, wt, g_w, g_b, rows, dx_out=None, act=ops.ACT_NONE, aux_in=None):
-        """dW = dy^T x (fp32, written in place), db = colsum(dy), dx = dy W (through the transposed shadow)"""
-        T, dev = dy.dtype, dy.device
-        rp = _r64(rows)
-        n_out, k_in = dy.shape[1], x.shape[1]
-        dyt = torch.empty(n_out, rp, device=dev, dtype=T)
-        ops.transpose_pad(dy, dyt, colsum=g_b, R=rows)
-        xt = torch.empty(k_in, rp, device=dev, dtype=T)
-        ops.transpose_pad(x, xt, R=rows)
-        ops.gemm_nt(dyt, xt, g_w, K=rp)
+        """dW = dy^T x: TN GEMM reading dy / x where they lie, split-K partials added atomically into the zeroed fp32
+        gradient; db = colsum(dy); dx = dy W through the transposed compute-dtype shadow (NT form, vector epilogue)."""
+        ops.gemm(dy, x, g_w, trans_a=True, trans_b=True, splitk=0, K=rows)
+        if g_b is not None:
+            ops.colsum(dy, g_b, R=rows)
         if dx_out is not None:
-            ops.gemm_nt(dy, wt, dx_out, act=act, aux_in=aux_in, M=rows)
+            ops.gemm(dy, wt, dx_out, act=act, aux_in=aux_in, M=rows)
         return dx_out
 
     def _backward_impl(self, s, d_last, d_pooled):

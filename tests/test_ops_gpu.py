@@ -94,6 +94,35 @@ def test_gemm_epilogues(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 8, 256), (197 * 3, 96, 160)])
+def test_gemm_layouts_and_splitk(ops, dtype, M, N, K):
+    """NN (dX = dY W) and TN (dW = dY^T X) read their operands where they lie; split-K adds partials atomically."""
+    a, bias = q(rnd(M, K, seed=1), dtype), rnd(N, seed=3)
+    bkn = q(rnd(K, N, seed=2), dtype)           # B stored [K, N]
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm(dev(a, dtype), dev(bkn, dtype), out, trans_b=True, bias=dev(bias))
+    assert rel(out, a @ bkn + bias) < TOL[dtype]
+    u = q(rnd(M, N, seed=5), dtype)
+    ur = u.clone().requires_grad_(True)
+    (ur * torch.sigmoid(1.702 * ur)).sum().backward()
+    ops.gemm(dev(a, dtype), dev(bkn, dtype), out, trans_b=True, act=ops.ACT_DQGELU, aux_in=dev(u, dtype))
+    assert rel(out, (a @ bkn) * ur.grad) < TOL[dtype]
+    # TN: reduction over the ROWS of both operands (K plays the role of the token count)
+    R = M
+    dy, x = q(rnd(R, N, seed=7), dtype), q(rnd(R, K, seed=8), dtype)
+    if N % 8 == 0 and K % 8 == 0:
+        for sk in (1, 0, 3):
+            dw = torch.zeros(N, K, device="cuda")
+            ops.gemm(dev(dy, dtype), dev(x, dtype), dw, trans_a=True, trans_b=True, splitk=sk)
+            assert rel(dw, dy.t() @ x) < TOL[dtype], sk
+    # NT with split-K
+    b = q(rnd(N, K, seed=9), dtype)
+    o32 = torch.zeros(M, N, device="cuda")
+    ops.gemm(dev(a, dtype), dev(b, dtype), o32, splitk=2, bias=dev(bias))
+    assert rel(o32, a @ b.t() + bias) < TOL[dtype]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_zero_padded_k(ops, dtype):
     """weight-gradient form: both operands are transposed copies zero-padded along K"""
     R, Ca, Cb = 197 * 3, 96, 160
