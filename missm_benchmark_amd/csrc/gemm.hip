@@ -36,15 +36,17 @@ struct GemmArgs {
   int splitk, k_per_split;  // splitk > 1: each K slice atomically adds its partial into the (zeroed) fp32 C
 };
 
+__device__ __attribute__((aligned(16))) unsigned int g_zero16[4];   // source of zero-filled LDS chunks
+
 // swizzle key of a k-major ("transposed") tile row: the 8 rows touched by one half-wave of a transposed fragment read
 // ({8g+q} and {8g+8+q}, q = 0..3) get 8 distinct keys -> 8 distinct 32-byte slots of the 256-byte bank row.
 __device__ __forceinline__ int tkey(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 template <int RBT> __device__ __forceinline__ int tswz(int row, int chunk16) { return row * RBT + ((chunk16 ^ (tkey(row) << 1)) << 4); }
 
-// fragment (one MFMA step) of a k-major tile [BK rows of k][128 columns]: lane (i, g) gets column c0 + i, its KPL k values
-template <typename T> struct KMajorFrag;
-template <> struct KMajorFrag<bf16> {
-  static constexpr int RBT = 256;
+// fragment (one MFMA step) of a k-major tile [BK rows of k][COLS columns]: lane (i, g) gets column c0 + i, its KPL k values
+template <typename T, int COLS> struct KMajorFrag;
+template <int COLS> struct KMajorFrag<bf16, COLS> {
+  static constexpr int RBT = COLS * 2;
   __device__ static __forceinline__ bf16x8 load(const char* lds, int ks, int c0, int lane) {
     const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
     const int r1 = ks * 32 + 8 * g + q, col = c0 + 4 * p;
@@ -57,8 +59,8 @@ template <> struct KMajorFrag<bf16> {
     return __builtin_bit_cast(bf16x8, v);
   }
 };
-template <> struct KMajorFrag<float> {
-  static constexpr int RBT = 512;
+template <int COLS> struct KMajorFrag<float, COLS> {
+  static constexpr int RBT = COLS * 4;
   __device__ static __forceinline__ f32x4 load(const char* lds, int ks, int c0, int lane) {
     const int i = lane & 15, g = lane >> 4, col = c0 + i;
     f32x4 v;
@@ -68,138 +70,12 @@ template <> struct KMajorFrag<float> {
   }
 };
 
-// TA: A is stored [K, M] (reduction index on rows); TB: B is stored [K, N].  TA = TB = false is the NT form.
-template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
-  using M_ = Mma<T>;
-  using Frag = typename M_::Frag;
-  constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
-  constexpr int BK = RB / sizeof(T);      // k elements per tile (64 bf16 / 32 f32)
-  constexpr int KSTEPS = BK / M_::KS;     // 2
-  constexpr int RBT = KMajorFrag<T>::RBT; // bytes per row of a k-major tile (128 elements)
-  constexpr int NCT = RBT / 16;           // 16-byte chunks per k-major row
-  constexpr int TILE_BYTES = BM * RB;     // 16 KiB either layout
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
-  char* ldsA = lds;                       // [2][TILE_BYTES]
-  char* ldsB = lds + 2 * TILE_BYTES;
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+// Epilogue of one wave's 64x64 accumulator block whose top-left element is (mw, nw).
+// !TB: lane owns rows 4*lg + r of each 16-row tile i and the 4 CONSECUTIVE columns 4*li + j  (vector accesses)
+//  TB: lane owns column 16*j + li of each n-tile j                                          (scalar accesses)
+template <typename T, bool TB>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane) {
   const int li = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int bid = blockIdx.x;
-  const int split = bid / ntiles;
-  const int logical = xcd_remap(bid - split * ntiles, ntiles);
-  const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
-  const int m0 = tm * BM, n0 = tn * BN;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-
-  const T* __restrict__ A = static_cast<const T*>(g.A);
-  const T* __restrict__ B = static_cast<const T*>(g.B);
-
-  // ---- staging: 4 x 16-byte chunks of A and of B per thread per K tile ----
-  int a_lds[4], b_lds[4];
-  const T* a_ptr[4];
-  const T* b_ptr[4];
-  bool a_ok[4], b_ok[4];
-  int a_kofs[4], b_kofs[4];   // k offset (inside the tile) this chunk covers, for the K-edge predicate
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    if constexpr (!TA) {
-      const int r = (tid >> 3) + 32 * i, c = tid & 7;
-      int gr = m0 + r; gr = gr < g.M ? gr : g.M - 1;
-      a_ptr[i] = A + (size_t)gr * g.lda + c * EPC;
-      a_lds[i] = swz<RB>(r, c * 16);
-      a_ok[i] = true; a_kofs[i] = c * EPC;
-    } else {
-      const int idx = tid + 256 * i, r = idx / NCT, c = idx % NCT;
-      a_ptr[i] = A + (size_t)r * g.lda + m0 + c * EPC;
-      a_lds[i] = tswz<RBT>(r, c);
-      a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = r;
-    }
-    if constexpr (!TB) {
-      const int r = (tid >> 3) + 32 * i, c = tid & 7;
-      // B tile row r (output column n0 + r) goes to LDS row pi(r) = 64*(r/64) + 16*(r%4) + (r%64)/4
-      const int lr = (r & 64) + ((r & 3) << 4) + ((r & 63) >> 2);
-      int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
-      b_ptr[i] = B + (size_t)gn * g.ldb + c * EPC;
-      b_lds[i] = swz<RB>(lr, c * 16);
-      b_ok[i] = true; b_kofs[i] = c * EPC;
-    } else {
-      const int idx = tid + 256 * i, r = idx / NCT, c = idx % NCT;
-      b_ptr[i] = B + (size_t)r * g.ldb + n0 + c * EPC;
-      b_lds[i] = tswz<RBT>(r, c);
-      b_ok[i] = (n0 + c * EPC) < g.N; b_kofs[i] = r;
-    }
-  }
-
-  u32x4 ra[4], rb[4];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const bool ain = a_ok[i] && (k0 + a_kofs[i]) < kend;
-      const bool bin = b_ok[i] && (k0 + b_kofs[i]) < kend;
-      ra[i] = u32x4{0, 0, 0, 0};
-      rb[i] = u32x4{0, 0, 0, 0};
-      if (ain) ra[i] = *reinterpret_cast<const u32x4*>(TA ? a_ptr[i] + (size_t)k0 * g.lda : a_ptr[i] + k0);
-      if (bin) rb[i] = *reinterpret_cast<const u32x4*>(TB ? b_ptr[i] + (size_t)k0 * g.ldb : b_ptr[i] + k0);
-    }
-  };
-  auto lstore = [&](int buf) {
-    char* la = ldsA + buf * TILE_BYTES;
-    char* lb = ldsB + buf * TILE_BYTES;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      *reinterpret_cast<u32x4*>(la + a_lds[i]) = ra[i];
-      *reinterpret_cast<u32x4*>(lb + b_lds[i]) = rb[i];
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk <= 0) return;
-  gload(kbeg);
-  lstore(0);
-  __syncthreads();
-
-  for (int kt = 0; kt < nk; ++kt) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) gload(kbeg + (kt + 1) * BK);   // next tile's loads fly under this tile's MFMAs
-    const char* la = ldsA + buf * TILE_BYTES;
-    const char* lb = ldsB + buf * TILE_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      Frag fa[4], fb[4];
-      const int cbyte = (ks * 4 + lg) * 16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (!TA) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
-        else fa[i] = KMajorFrag<T>::load(la, ks, wm * 64 + i * 16, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (!TB) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
-        else fb[j] = KMajorFrag<T>::load(lb, ks, wn * 64 + j * 16, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
-    }
-    if (kt + 1 < nk) lstore(buf ^ 1);
-    __syncthreads();
-  }
-
-  // ---- epilogue ----
-  // !TB: lane owns rows 4*lg + r of each 16-row tile i and the 4 CONSECUTIVE columns 4*li + j  (vector accesses)
-  //  TB: lane owns column 16*j + li of each n-tile j                                          (scalar accesses)
   const bool first_split = split == 0;
   auto finish = [&](float x, size_t off, size_t aoff) -> void {   // scalar tail of the epilogue for one element
     if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
@@ -225,20 +101,19 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
   if constexpr (TB) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int col = n0 + wn * 64 + j * 16 + li;
+      const int col = nw + j * 16 + li;
       if (col >= g.N) continue;
       const float bv = (g.bias && first_split) ? g.bias[col] : 0.f;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+          const int row = mw + i * 16 + lg * 4 + r;
           if (row < g.M) finish(acc[i][j][r] * g.alpha + bv, (size_t)row * g.ldc + col, (size_t)row * g.ldaux + col);
         }
     }
-    return;
   } else {
-    const int col = n0 + wn * 64 + li * 4;
+    const int col = nw + li * 4;
     if (col >= g.N) return;
     const bool full4 = (col + 3 < g.N) && g.vec_ok && g.splitk == 1;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -251,7 +126,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
     for (int i = 0; i < 4; ++i) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = m0 + wm * 64 + i * 16 + lg * 4 + r;
+        const int row = mw + i * 16 + lg * 4 + r;
         if (row >= g.M) continue;
         f32x4 v;
 #pragma unroll
@@ -286,6 +161,276 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+// TA: A is stored [K, M] (reduction index on rows); TB: B is stored [K, N].  TA = TB = false is the NT form.
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
+  constexpr int BK = RB / sizeof(T);      // k elements per tile (64 bf16 / 32 f32)
+  constexpr int KSTEPS = BK / M_::KS;     // 2
+  constexpr int RBT = KMajorFrag<T, 128>::RBT; // bytes per row of a k-major tile (128 elements)
+  constexpr int NCT = RBT / 16;           // 16-byte chunks per k-major row
+  constexpr int TILE_BYTES = BM * RB;     // 16 KiB either layout
+  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+  char* ldsA = lds;                       // [2][TILE_BYTES]
+  char* ldsB = lds + 2 * TILE_BYTES;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int split = bid / ntiles;
+  const int logical = xcd_remap(bid - split * ntiles, ntiles);
+  const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
+  const int m0 = tm * BM, n0 = tn * BN;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  const T* __restrict__ A = static_cast<const T*>(g.A);
+  const T* __restrict__ B = static_cast<const T*>(g.B);
+
+  // ---- staging: global -> LDS directly (global_load_lds_dwordx4, no VGPR round trip, no ds_write).  One wave
+  // instruction fills 1 KiB of LDS linearly (wave-uniform base + 16 B * lane); the swizzle is applied by choosing which
+  // global chunk each lane fetches.  4 pieces of A and 4 of B per wave per K tile.  Out-of-range chunks (K edge, ragged
+  // M/N of a k-major operand) are fetched from a 16-byte zero block instead.
+  const T* a_src[4];
+  const T* b_src[4];
+  bool a_ok[4], b_ok[4];
+  int a_kofs[4], b_kofs[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pi = wave * 4 + i;
+    if constexpr (!TA) {
+      const int row = 8 * pi + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
+      a_src[i] = A + (size_t)gr * g.lda + c * EPC;
+      a_ok[i] = true; a_kofs[i] = c * EPC;
+    } else {
+      constexpr int RPP = 1024 / RBT;
+      const int row = RPP * pi + lane / NCT, c = (lane % NCT) ^ (tkey(row) << 1);
+      a_src[i] = A + (size_t)row * g.lda + m0 + c * EPC;
+      a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = row;
+    }
+    if constexpr (!TB) {
+      const int lr = 8 * pi + (lane >> 3), c = (lane & 7) ^ (lr & 7);
+      // LDS row lr holds tile row r (output column n0 + r) with lr = 64*(r/64) + 16*(r%4) + (r%64)/4
+      const int r = (lr & 64) + ((lr & 15) << 2) + ((lr >> 4) & 3);
+      int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
+      b_src[i] = B + (size_t)gn * g.ldb + c * EPC;
+      b_ok[i] = true; b_kofs[i] = c * EPC;
+    } else {
+      constexpr int RPP = 1024 / RBT;
+      const int row = RPP * pi + lane / NCT, c = (lane % NCT) ^ (tkey(row) << 1);
+      b_src[i] = B + (size_t)row * g.ldb + n0 + c * EPC;
+      b_ok[i] = (n0 + c * EPC) < g.N; b_kofs[i] = row;
+    }
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  auto stage = [&](int buf, int k0) {
+    char* la = ldsA + buf * TILE_BYTES + wave * 4096;
+    char* lb = ldsB + buf * TILE_BYTES + wave * 4096;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T* pa = (a_ok[i] && (k0 + a_kofs[i]) < kend) ? (TA ? a_src[i] + (size_t)k0 * g.lda : a_src[i] + k0)
+                                                          : reinterpret_cast<const T*>(g_zero16);
+      const T* pb = (b_ok[i] && (k0 + b_kofs[i]) < kend) ? (TB ? b_src[i] + (size_t)k0 * g.ldb : b_src[i] + k0)
+                                                          : reinterpret_cast<const T*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(la + i * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(lb + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  stage(0, kbeg);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);   // next tile lands in the other buffer under this tile's MFMAs
+    const char* la = ldsA + buf * TILE_BYTES;
+    const char* lb = ldsB + buf * TILE_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag fa[4], fb[4];
+      const int cbyte = (ks * 4 + lg) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (!TA) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
+        else fa[i] = KMajorFrag<T, 128>::load(la, ks, wm * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (!TB) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
+        else fb[j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 256x128 tile, 8 waves (4 x 2, 64x64 each), 3-stage LDS ring filled by global_load_lds with TWO K tiles in flight:
+//   loop:  s_waitcnt vmcnt(6)   -> this wave's 6 pieces of tile kt have landed (tile kt+1 stays in flight)
+//          s_barrier            -> everybody's pieces landed; everybody is done reading the stage tile kt+2 will overwrite
+//          issue tile kt+2      -> 6 x global_load_lds_dwordx4 per wave
+//          32 MFMA + 16 LDS fragment reads on tile kt
+// One barrier per K tile, never a vmcnt(0) inside the loop, all LDS in one (dynamic) array.  144 KiB of LDS -> one
+// 512-thread workgroup per CU (2 waves per SIMD); 0.75x the L2->LDS bytes per FLOP of the 128x128 kernel.
+// (A persistent variant that keeps the ring running across output tiles was measured SLOWER - 845 -> 665 TFLOP/s at
+//  4096^3 - because the counted vmcnt then also waits for the previous tile's epilogue stores.)
+// ---------------------------------------------------------------------------------------------------
+constexpr int G3_BM = 256, G3_BN = 128, G3_THREADS = 512, G3_STAGES = 3;
+constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * RB;   // 48 KiB
+constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
+
+template <typename T, bool TA, bool TB>
+__global__ __launch_bounds__(G3_THREADS, 2) void gemm3_kernel(GemmArgs g) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int EPC = 16 / sizeof(T);
+  constexpr int BK = RB / sizeof(T);
+  constexpr int KSTEPS = BK / M_::KS;
+  constexpr int RBTA = KMajorFrag<T, G3_BM>::RBT, NCTA = RBTA / 16;   // k-major A tile rows: 256 elements
+  constexpr int RBTB = KMajorFrag<T, G3_BN>::RBT, NCTB = RBTB / 16;   // k-major B tile rows: 128 elements
+  constexpr int A_BYTES = G3_BM * RB;                                 // 32 KiB either layout
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int bid = blockIdx.x;
+  const int split = bid / ntiles;
+  const int logical = xcd_remap(bid - split * ntiles, ntiles);
+  const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
+  const int m0 = tm * G3_BM, n0 = tn * G3_BN;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+
+  const T* __restrict__ A = static_cast<const T*>(g.A);
+  const T* __restrict__ B = static_cast<const T*>(g.B);
+
+  // staging: A tile = 32 pieces of 1 KiB (4 per wave), B tile = 16 pieces (2 per wave)
+  const T* a_src[4];
+  const T* b_src[2];
+  bool a_ok[4], b_ok[2];
+  int a_kofs[4], b_kofs[2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int pi = wave * 4 + i;
+    if constexpr (!TA) {
+      const int row = 8 * pi + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
+      a_src[i] = A + (size_t)gr * g.lda + c * EPC;
+      a_ok[i] = true; a_kofs[i] = c * EPC;
+    } else {
+      constexpr int RPP = 1024 / RBTA;     // 2 (bf16) or 1 (f32) k rows per piece
+      const int row = RPP * pi + lane / NCTA, c = (lane % NCTA) ^ (tkey(row) << 1);
+      a_src[i] = A + (size_t)row * g.lda + m0 + c * EPC;
+      a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = row;
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int pi = wave * 2 + i;
+    if constexpr (!TB) {
+      const int lr = 8 * pi + (lane >> 3), c = (lane & 7) ^ (lr & 7);
+      const int r = (lr & 64) + ((lr & 15) << 2) + ((lr >> 4) & 3);
+      int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
+      b_src[i] = B + (size_t)gn * g.ldb + c * EPC;
+      b_ok[i] = true; b_kofs[i] = c * EPC;
+    } else {
+      constexpr int RPP = 1024 / RBTB;
+      const int row = RPP * pi + lane / NCTB, c = (lane % NCTB) ^ (tkey(row) << 1);
+      b_src[i] = B + (size_t)row * g.ldb + n0 + c * EPC;
+      b_ok[i] = (n0 + c * EPC) < g.N; b_kofs[i] = row;
+    }
+  }
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  auto stage = [&](int st, int k0) {
+    char* la = lds + st * G3_STAGE_BYTES + wave * 4096;
+    char* lb = lds + st * G3_STAGE_BYTES + A_BYTES + wave * 2048;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const T* pa = (a_ok[i] && (k0 + a_kofs[i]) < kend) ? (TA ? a_src[i] + (size_t)k0 * g.lda : a_src[i] + k0)
+                                                          : reinterpret_cast<const T*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(la + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const T* pb = (b_ok[i] && (k0 + b_kofs[i]) < kend) ? (TB ? b_src[i] + (size_t)k0 * g.ldb : b_src[i] + k0)
+                                                          : reinterpret_cast<const T*>(g_zero16);
+      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(lb + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int nk = (kend - kbeg + BK - 1) / BK;
+  if (nk <= 0) return;
+  stage(0, kbeg);
+  if (nk > 1) stage(1, kbeg + BK);
+
+  int st = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (kt + 2 < nk) {
+      int st2 = st + 2; st2 = st2 >= G3_STAGES ? st2 - G3_STAGES : st2;
+      stage(st2, kbeg + (kt + 2) * BK);
+    }
+    const char* la = lds + st * G3_STAGE_BYTES;
+    const char* lb = la + A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      Frag fa[4], fb[4];
+      const int cbyte = (ks * 4 + lg) * 16;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (!TA) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
+        else fa[i] = KMajorFrag<T, G3_BM>::load(la, ks, wm * 64 + i * 16, lane);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if constexpr (!TB) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
+        else fb[j] = KMajorFrag<T, G3_BN>::load(lb, ks, wn * 64 + j * 16, lane);
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
+    }
+    st = st + 1 >= G3_STAGES ? 0 : st + 1;
+  }
+  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -388,15 +533,18 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate;
-  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
+  const bool big = M >= 192;   // 256x128 tiles, 3-stage ring; small problems keep the 128x128 kernel
+  const int bm = big ? G3_BM : BM;
+  g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
              ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
   const int bk = dtype == kBF16 ? 64 : 32;
   const int tiles = g.tiles_m * g.tiles_n;
-  if (splitk <= 0) {  // auto: only worth it when the tile grid cannot fill the 256 CUs at 2 workgroups each
+  const int fill = big ? 256 : 512;   // workgroups that fill the chip once (1 resp. 2 per CU)
+  if (splitk <= 0) {  // auto: only worth it when the tile grid cannot fill the 256 CUs
     splitk = 1;
-    if (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE && tiles < 256) {
-      splitk = 512 / tiles;
+    if (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE && tiles < fill) {
+      splitk = (2 * fill) / tiles;
       const int maxs = K / (8 * bk);
       if (splitk > maxs) splitk = maxs;
       if (splitk < 1) splitk = 1;
@@ -408,8 +556,33 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   kps = (kps + bk - 1) / bk * bk;
   splitk = (K + kps - 1) / kps;
   g.splitk = splitk; g.k_per_split = kps;
-  dim3 grid(tiles * splitk), block(GEMM_THREADS);
   hipStream_t s = static_cast<hipStream_t>(stream);
+  if (big) {
+    dim3 grid(tiles * splitk), block(G3_THREADS);
+#define MISSM_GEMM3_LAUNCH(T, TA, TB)                                                                                   \
+    do {                                                                                                                \
+      static bool attr_done = false;                                                                                    \
+      if (!attr_done) {                                                                                                 \
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<T, TA, TB>),                       \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);                   \
+        if (e != hipSuccess) { missm_set_error("gemm: cannot reserve %d bytes of LDS: %s", G3_LDS_BYTES, hipGetErrorString(e)); return MISSM_ERR_LAUNCH; } \
+        attr_done = true;                                                                                               \
+      }                                                                                                                 \
+      hipLaunchKernelGGL((gemm3_kernel<T, TA, TB>), grid, block, G3_LDS_BYTES, s, g);                                    \
+    } while (0)
+    if (dtype == kBF16) {
+      if (!trans_a && !trans_b) MISSM_GEMM3_LAUNCH(bf16, false, false);
+      else if (!trans_a && trans_b) MISSM_GEMM3_LAUNCH(bf16, false, true);
+      else MISSM_GEMM3_LAUNCH(bf16, true, true);
+    } else {
+      if (!trans_a && !trans_b) MISSM_GEMM3_LAUNCH(float, false, false);
+      else if (!trans_a && trans_b) MISSM_GEMM3_LAUNCH(float, false, true);
+      else MISSM_GEMM3_LAUNCH(float, true, true);
+    }
+#undef MISSM_GEMM3_LAUNCH
+    return missm_check_launch("gemm3");
+  }
+  dim3 grid(tiles * splitk), block(GEMM_THREADS);
 #define MISSM_GEMM_LAUNCH(T, TA, TB) hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, block, 0, s, g)
   if (dtype == kBF16) {
     if (!trans_a && !trans_b) MISSM_GEMM_LAUNCH(bf16, false, false);
