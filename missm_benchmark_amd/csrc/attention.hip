@@ -35,17 +35,29 @@ __device__ __forceinline__ size_t seq_base(const AttnArgs& a, int q) {
 constexpr int HD = 64;
 constexpr float kNegInf = -__builtin_huge_valf();
 
-// stage `rows` (zero-filled up to LP) of one head's [L, 64] slice into a swizzled LDS tile
+__device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4];   // source of zero-filled LDS chunks
+
+// stage L rows (zero-filled up to LP) of one head's [L, 64] slice into a swizzled LDS tile with global_load_lds:
+// every 1-KiB piece is one wave instruction, all pieces of the tile are in flight together (no VGPR round trip);
+// the caller waits with vmcnt(0) + barrier.  LDS position (row, chunk c') holds source chunk c' ^ (row & M).
 template <typename T, int RBv>
 __device__ __forceinline__ void stage_head(char* lds, const T* src, size_t base, int tok_stride, int ld, int col0, int L, int LP,
                                            int tid) {
-  constexpr int NC = RBv / 16, EPC = 16 / sizeof(T);
-  for (int idx = tid; idx < LP * NC; idx += 256) {
-    const int row = idx / NC, c = idx % NC;
-    u32x4 v = {0, 0, 0, 0};
-    if (row < L) v = *reinterpret_cast<const u32x4*>(src + (base + (size_t)row * tok_stride) * ld + col0 + c * EPC);
-    *reinterpret_cast<u32x4*>(lds + swz<RBv>(row, c * 16)) = v;
+  constexpr int NC = RBv / 16, EPC = 16 / sizeof(T), RPP = 1024 / RBv, M = (NC - 1) & 7;
+  using gptr = const __attribute__((address_space(1))) void*;
+  using lptr = __attribute__((address_space(3))) void*;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int npieces = LP / RPP;
+  for (int pi = wave; pi < npieces; pi += 4) {
+    const int row = pi * RPP + lane / NC, c = (lane % NC) ^ (row & M);
+    const T* p = (row < L) ? src + (base + (size_t)row * tok_stride) * ld + col0 + c * EPC
+                           : reinterpret_cast<const T*>(g_attn_zero16);
+    __builtin_amdgcn_global_load_lds((gptr)p, (lptr)(lds + pi * 1024), 16, 0, 0);
   }
+}
+__device__ __forceinline__ void stage_wait() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
 }
 
 template <typename T, int NTP>
@@ -71,7 +83,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
   stage_head<T, RBv>(ldsV, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
   for (int k = tid; k < LP; k += 256)
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
-  __syncthreads();
+  stage_wait();
 
   const int nqt = (L + 15) / 16;
   for (int qt = wave; qt < nqt; qt += 4) {
@@ -161,7 +173,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
     lseL[k] = k < L ? lse[k] : __builtin_huge_valf();
     Dl[k] = 0.f;
   }
-  __syncthreads();
+  stage_wait();
 
   // ---------------- pass A: query on the lane -> dQ, D ----------------
   const int nt = (L + 15) / 16;
@@ -224,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   // ---------------- pass B: key on the lane -> dK, dV ----------------
   stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, tid);
   stage_head<T, RBv>(X1, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, tid);
-  __syncthreads();
+  stage_wait();
   for (int kt = wave; kt < nt; kt += 4) {
     const int key = kt * 16 + li;
     const bool kin = key < L;
@@ -289,11 +301,15 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 // packs 64 / L (sequence, head) pairs, lane = (pair, query); operands sit in LDS as T, math in fp32.
 // HBM-bound by construction (3 KB in, 1 KB out per pair at L = 8).
 // ---------------------------------------------------------------------------------------------------
+// LDS rows of the small path are padded by 16 bytes: a lane reads ITS OWN row (stride = row pitch), and an unpadded
+// 128-byte pitch would put all 64 lanes on the same banks.
+template <typename T> __device__ __forceinline__ int small_pitch(int hd) { return hd + 16 / (int)sizeof(T); }
+
 template <typename T>
 __device__ __forceinline__ void stage_small(T* dst, const T* src, const AttnArgs& a, int pair0, int npairs_total, int PW, int hd,
                                             int ld, int col_base, int lane) {
   constexpr int EPC = 16 / sizeof(T);
-  const int NC = hd / EPC;
+  const int NC = hd / EPC, hp = small_pitch<T>(hd);
   const int L = a.L;
   for (int idx = lane; idx < PW * L * NC; idx += 64) {
     const int rowid = idx / NC, c = idx % NC;
@@ -305,7 +321,7 @@ __device__ __forceinline__ void stage_small(T* dst, const T* src, const AttnArgs
       const size_t row = seq_base(a, seq) + (size_t)j * a.tok_stride;
       v = *reinterpret_cast<const u32x4*>(src + row * ld + col_base + h * hd + c * EPC);
     }
-    *reinterpret_cast<u32x4*>(dst + (size_t)rowid * hd + c * EPC) = v;
+    *reinterpret_cast<u32x4*>(dst + (size_t)rowid * hp + c * EPC) = v;
   }
 }
 
@@ -315,9 +331,10 @@ __global__ __launch_bounds__(64) void attn_small_fwd_kernel(AttnArgs a, int hd) 
   const int L = a.L, PW = 64 / L, lane = threadIdx.x;
   const int total = a.nseq * a.H;
   const int pair0 = blockIdx.x * PW;
+  const int hp = small_pitch<T>(hd);
   T* sQ = reinterpret_cast<T*>(smem);
-  T* sK = sQ + (size_t)PW * L * hd;
-  T* sV = sK + (size_t)PW * L * hd;
+  T* sK = sQ + (size_t)PW * L * hp;
+  T* sV = sK + (size_t)PW * L * hp;
   const T* qkv = static_cast<const T*>(a.qkv);
   stage_small<T>(sQ, qkv, a, pair0, total, PW, hd, a.ld, 0, lane);
   stage_small<T>(sK, qkv, a, pair0, total, PW, hd, a.ld, a.d, lane);
@@ -326,9 +343,9 @@ __global__ __launch_bounds__(64) void attn_small_fwd_kernel(AttnArgs a, int hd) 
   const int pl = lane / L, q = lane % L, pair = pair0 + pl;
   if (pl >= PW || pair >= total) return;
   const int seq = pair / a.H, h = pair % a.H;
-  const T* Qr = sQ + ((size_t)pl * L + q) * hd;
-  const T* Kp = sK + (size_t)pl * L * hd;
-  const T* Vp = sV + (size_t)pl * L * hd;
+  const T* Qr = sQ + ((size_t)pl * L + q) * hp;
+  const T* Kp = sK + (size_t)pl * L * hp;
+  const T* Vp = sV + (size_t)pl * L * hp;
   float s[MAXL];
   float mx = kNegInf;
 #pragma unroll
@@ -337,7 +354,7 @@ __global__ __launch_bounds__(64) void attn_small_fwd_kernel(AttnArgs a, int hd) 
     if (j < L) {
       float acc = 0.f;
       for (int d0 = 0; d0 < hd; d0 += 4) {
-        const f32x4 qv = load4(Qr + d0), kv = load4(Kp + (size_t)j * hd + d0);
+        const f32x4 qv = load4(Qr + d0), kv = load4(Kp + (size_t)j * hp + d0);
         acc += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
       }
       bool ok = !(a.causal && j > q);
@@ -357,7 +374,7 @@ __global__ __launch_bounds__(64) void attn_small_fwd_kernel(AttnArgs a, int hd) 
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int j = 0; j < MAXL; ++j)
-      if (j < L) { const f32x4 vv = load4(Vp + (size_t)j * hd + d0); acc += vv * s[j]; }
+      if (j < L) { const f32x4 vv = load4(Vp + (size_t)j * hp + d0); acc += vv * s[j]; }
     acc *= inv;
     store4(out + d0, acc);
   }
@@ -369,7 +386,8 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) 
   const int L = a.L, PW = 64 / L, lane = threadIdx.x;
   const int total = a.nseq * a.H;
   const int pair0 = blockIdx.x * PW;
-  const size_t mat = (size_t)PW * L * hd;
+  const int hp = small_pitch<T>(hd);
+  const size_t mat = (size_t)PW * L * hp;
   T* sQ = reinterpret_cast<T*>(smem);
   T* sK = sQ + mat;
   T* sV = sK + mat;
@@ -385,10 +403,10 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) 
   const int pl = lane / L, q = lane % L, pair = pair0 + pl;
   const bool active = pl < PW && pair < total;
   const int seq = active ? pair / a.H : 0, h = active ? pair % a.H : 0;
-  const T* Qp = sQ + (size_t)pl * L * hd;
-  const T* Kp = sK + (size_t)pl * L * hd;
-  const T* Vp = sV + (size_t)pl * L * hd;
-  const T* dOp = sdO + (size_t)pl * L * hd;
+  const T* Qp = sQ + (size_t)pl * L * hp;
+  const T* Kp = sK + (size_t)pl * L * hp;
+  const T* Vp = sV + (size_t)pl * L * hp;
+  const T* dOp = sdO + (size_t)pl * L * hp;
   T* dqkv = static_cast<T*>(a.dqkv);
   if (active) {
     float p[MAXL], dp[MAXL];
@@ -399,8 +417,8 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) 
       if (j < L) {
         float acc = 0.f, acc2 = 0.f;
         for (int d0 = 0; d0 < hd; d0 += 4) {
-          const f32x4 qv = load4(Qp + (size_t)q * hd + d0), kv = load4(Kp + (size_t)j * hd + d0);
-          const f32x4 gv = load4(dOp + (size_t)q * hd + d0), vv = load4(Vp + (size_t)j * hd + d0);
+          const f32x4 qv = load4(Qp + (size_t)q * hp + d0), kv = load4(Kp + (size_t)j * hp + d0);
+          const f32x4 gv = load4(dOp + (size_t)q * hp + d0), vv = load4(Vp + (size_t)j * hp + d0);
           acc += qv[0] * kv[0] + qv[1] * kv[1] + qv[2] * kv[2] + qv[3] * kv[3];
           acc2 += gv[0] * vv[0] + gv[1] * vv[1] + gv[2] * vv[2] + gv[3] * vv[3];
         }
@@ -432,7 +450,7 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) 
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int j = 0; j < MAXL; ++j)
-        if (j < L) { const f32x4 kv = load4(Kp + (size_t)j * hd + d0); acc += kv * dp[j]; }
+        if (j < L) { const f32x4 kv = load4(Kp + (size_t)j * hp + d0); acc += kv * dp[j]; }
       store4(dq + d0, acc);
     }
   }
@@ -444,7 +462,7 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) 
       f32x4 ak = {0.f, 0.f, 0.f, 0.f}, av = {0.f, 0.f, 0.f, 0.f};
       for (int i = 0; i < L; ++i) {
         const float dsv = sdS[((size_t)pl * L + i) * L + q], pv = sP[((size_t)pl * L + i) * L + q];
-        const f32x4 qv = load4(Qp + (size_t)i * hd + d0), gv = load4(dOp + (size_t)i * hd + d0);
+        const f32x4 qv = load4(Qp + (size_t)i * hp + d0), gv = load4(dOp + (size_t)i * hp + d0);
         ak += qv * dsv;
         av += gv * pv;
       }
@@ -482,7 +500,7 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
     const int PW = 64 / L;
     const int total = a.nseq * a.H;
     dim3 grid((total + PW - 1) / PW), block(64);
-    size_t shmem = (size_t)PW * L * hd * sizeof(T) * (BWD ? 4 : 3) + (BWD ? (size_t)PW * L * L * 8 : 0);
+    size_t shmem = (size_t)PW * L * (hd + 16 / sizeof(T)) * sizeof(T) * (BWD ? 4 : 3) + (BWD ? (size_t)PW * L * L * 8 : 0);
 #define MISSM_SMALL(MAXL)                                                                                   \
     do {                                                                                                    \
       auto k = BWD ? attn_small_bwd_kernel<T, MAXL> : attn_small_fwd_kernel<T, MAXL>;                         \

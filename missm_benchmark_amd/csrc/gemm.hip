@@ -533,7 +533,9 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate;
-  const bool big = M >= 192;   // 256x128 tiles, 3-stage ring; small problems keep the 128x128 kernel
+  // 256x128 / 3-stage kernel: wins for long reductions on a full chip (845 vs ~750 TFLOP/s at 4096^3); at K = 768 its
+  // one-workgroup-per-CU fill/drain costs what the deeper pipeline gains, and split-K slices prefer 2 workgroups per CU.
+  const bool big = !trans_a && M >= 1024 && K >= 2048 && ((M + G3_BM - 1) / G3_BM) * ((N + BN - 1) / BN) >= 192;
   const int bm = big ? G3_BM : BM;
   g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&

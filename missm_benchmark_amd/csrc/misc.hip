@@ -120,16 +120,18 @@ __device__ __forceinline__ float eff_dy(const float* dy, const float* relu_y, co
   return g;
 }
 
-// dx[b, i] = sum_o dyeff[b, o] w[o, i]
+// dx[b, i] (+)= sum_o dyeff[b, o] w[o, i] ; the reduction over o is split across blockIdx.y (32 outputs per slice,
+// partial sums added atomically into a zeroed / accumulated dx) so the launch fills the chip instead of 96 workgroups
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
                                                              const long* __restrict__ row_code, long code, int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * I) return;
   const int b = idx / I, i = idx % I;
+  const int o0 = blockIdx.y * 32, o1 = min(O, o0 + 32);
   float acc = 0.f;
-  for (int o = 0; o < O; ++o) acc += eff_dy(dy, relu_y, row_code, code, b, o, O) * w[(long)o * I + i];
-  dx[idx] = accumulate ? dx[idx] + acc : acc;
+  for (int o = o0; o < o1; ++o) acc += eff_dy(dy, relu_y, row_code, code, b, o, O) * w[(long)o * I + i];
+  atomicAdd(dx + idx, acc);
 }
 
 // dw[o, i] = sum_b dyeff[b, o] x[b, i] ; dbias[o] = sum_b dyeff[b, o]
@@ -317,7 +319,10 @@ extern "C" int missm_small_linear_bwd(const float* dy, const float* x, const flo
                                       float* dbias, int B, int I, int O, const long* row_code, long code, int accumulate_dx,
                                       void* stream) {
   MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0, "small_linear_bwd: bad shape");
-  if (dx) hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, row_code, code, accumulate_dx);
+  if (dx) {
+    if (!accumulate_dx) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * I, S_(stream)) != hipSuccess) { missm_set_error("small_linear_bwd: memset failed"); return MISSM_ERR_LAUNCH; } }
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, row_code, code, accumulate_dx);
+  }
   if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, row_code, code);
   return missm_check_launch("small_linear_bwd");
 }

@@ -131,6 +131,8 @@ class LanguageBind(nn.Module):
                  compute_dtype: torch.dtype = torch.bfloat16, seed: int = 0):
         super().__init__()
         self.use_temp = use_temp
+        self.parallel_streams = True
+        self._streams = {}
         encoders, projs = {}, {}
         self.modality_scale = {}   # plain dict on purpose: un-registered in the reference too (languagebind/__init__.py:60,67)
         self.modality_config = {}
@@ -159,15 +161,35 @@ class LanguageBind(nn.Module):
             t.set_compute_dtype(dtype)
         return self
 
+    def _embed(self, key, value):
+        pooled = self.modality_encoder[key](**value)[1]
+        emb = self.modality_proj[key](pooled)
+        scale = 1.0
+        if self.use_temp and key != "language":
+            scale = float(self.modality_scale[key].detach().exp())
+        return hnn.l2norm_scale(emb, scale)
+
     def forward(self, inputs):
+        """Same contract as the reference loop (languagebind/__init__.py:75-85).  The reference encodes the modalities one
+        after the other on one stream; here every modality's tower is enqueued on its own HIP stream, so the under-filled
+        launches of the B x 197-token towers (150-600 workgroups on 256 CUs) overlap each other and the video tower.
+        autograd replays each tower's backward on the stream its forward ran on."""
+        dev = next(iter(self.modality_proj.values())).weight.device
+        if dev.type != "cuda" or not self.parallel_streams or len(inputs) < 2:
+            return {key: self._embed(key, value) for key, value in inputs.items()}
+        main = torch.cuda.current_stream()
         outputs = {}
         for key, value in inputs.items():
-            pooled = self.modality_encoder[key](**value)[1]
-            emb = self.modality_proj[key](pooled)
-            scale = 1.0
-            if self.use_temp and key != "language":
-                scale = float(self.modality_scale[key].detach().exp())
-            outputs[key] = hnn.l2norm_scale(emb, scale)
+            st = self._streams.get(key)
+            if st is None:
+                st = self._streams[key] = torch.cuda.Stream(device=dev)
+            st.wait_stream(main)
+            with torch.cuda.stream(st):
+                out = self._embed(key, value)
+            out.record_stream(main)
+            outputs[key] = out
+        for key in inputs:
+            main.wait_stream(self._streams[key])
         return outputs
 
 

@@ -45,7 +45,7 @@ def q(t, dtype):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 5, 256), (64, 2304, 64)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 5, 256), (64, 2304, 64), (4096, 1536, 2048)])
 def test_gemm_bias(ops, dtype, M, N, K):
     a, b, bias = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2), dtype), rnd(N, seed=3)
     out = torch.empty(M, N, device="cuda", dtype=dtype)
@@ -94,7 +94,7 @@ def test_gemm_epilogues(ops, dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 8, 256), (197 * 3, 96, 160)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 8, 256), (197 * 3, 96, 160), (4096, 1536, 2048)])
 def test_gemm_layouts_and_splitk(ops, dtype, M, N, K):
     """NN (dX = dY W) and TN (dW = dY^T X) read their operands where they lie; split-K adds partials atomically."""
     a, bias = q(rnd(M, K, seed=1), dtype), rnd(N, seed=3)
