@@ -474,18 +474,49 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
   if (c >= C) return;
   const int rbeg = blockIdx.x * rows_per_block;
   const int rend = min(R, rbeg + rows_per_block);
-  if (mod == 1) {
-    float s = 0.f;
-    for (int r = rbeg; r < rend; ++r) s += to_f32(in[(size_t)r * ld + c]);
-    atomicAdd(out + c, s);
-  } else {
-    int cur = -1; float s = 0.f;
-    for (int r = rbeg; r < rend; ++r) {
-      const int gidx = (r / div) % mod;
-      if (gidx != cur) { if (cur >= 0) atomicAdd(out + (size_t)cur * C + c, s); cur = gidx; s = 0.f; }
-      s += to_f32(in[(size_t)r * ld + c]);
+  int cur = -1; float s = 0.f;
+  for (int r = rbeg; r < rend; ++r) {
+    const int gidx = (r / div) % mod;
+    if (gidx != cur) { if (cur >= 0) atomicAdd(out + (size_t)cur * C + c, s); cur = gidx; s = 0.f; }
+    s += to_f32(in[(size_t)r * ld + c]);
+  }
+  if (cur >= 0) atomicAdd(out + (size_t)cur * C + c, s);
+}
+
+// plain column sum (bias gradients), HBM-bound: 16-byte loads, 8 row-lanes x 32 column-groups per workgroup, each
+// workgroup reduces a 256-row x (32 * VEC)-column panel through LDS and issues one atomic per column.
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int C, int ld) {
+  constexpr int VEC = 16 / sizeof(T);
+  __shared__ float red[8][32 * VEC + 1];
+  const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c0 = (blockIdx.y * 32 + cg) * VEC;
+  const int rbeg = blockIdx.x * 256;
+  const int rend = min(R, rbeg + 256);
+  float acc[VEC];
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+  if (c0 < C) {
+    for (int r = rbeg + rl; r < rend; r += 8) {
+      const T* p = in + (size_t)r * ld + c0;
+#pragma unroll
+      for (int j = 0; j < VEC; j += 4) {
+        const f32x4 v = load4(p + j);
+        acc[j] += v[0]; acc[j + 1] += v[1]; acc[j + 2] += v[2]; acc[j + 3] += v[3];
+      }
     }
-    if (cur >= 0) atomicAdd(out + (size_t)cur * C + c, s);
+  }
+#pragma unroll
+  for (int j = 0; j < VEC; ++j) red[rl][cg * VEC + j] = acc[j];
+  __syncthreads();
+  for (int i = threadIdx.x; i < 32 * VEC; i += 256) {
+    const int c = blockIdx.y * 32 * VEC + i;
+    if (c < C) {
+      float s = 0.f;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s += red[k][i];
+      atomicAdd(out + c, s);
+    }
   }
 }
 
@@ -621,10 +652,17 @@ extern "C" int missm_transpose_pad(const void* in, void* out, int R, int C, int 
 
 extern "C" int missm_colsum(const void* in, float* out, int R, int C, int ld, int div, int mod, int dtype, void* stream) {
   MISSM_CHECK_ARG(R > 0 && C > 0 && div > 0 && mod > 0, "colsum: bad shape");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int vec = dtype == kBF16 ? 8 : 4;
+  if (mod == 1 && C % vec == 0 && ld % vec == 0 && ((uintptr_t)in % 16 == 0)) {
+    dim3 grid((R + 255) / 256, (C + 32 * vec - 1) / (32 * vec)), block(256);
+    if (dtype == kBF16) hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, block, 0, s, (const bf16*)in, out, R, C, ld);
+    else hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, block, 0, s, (const float*)in, out, R, C, ld);
+    return missm_check_launch("colsum_vec");
+  }
   int rpb = 128;
   if (mod > 1 && div > 1) rpb = div;            // one group per block when groups are row runs
   dim3 grid((R + rpb - 1) / rpb, (C + 255) / 256), block(256);
-  hipStream_t s = static_cast<hipStream_t>(stream);
   if (dtype == kBF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)in, out, R, C, ld, div, mod, rpb);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)in, out, R, C, ld, div, mod, rpb);
   return missm_check_launch("colsum");
