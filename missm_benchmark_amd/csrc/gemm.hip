@@ -13,6 +13,7 @@
 #include "common.h"
 #include "mma.h"
 #include "missm_internal.h"
+#include <stdlib.h>
 
 namespace missm {
 
@@ -164,16 +165,26 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
 }
 
 // TA: A is stored [K, M] (reduction index on rows); TB: B is stored [K, N].  TA = TB = false is the NT form.
-template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
+// k-contiguous LDS rows hold RBK bytes: 128 (K tile 64 bf16, 64 KiB of LDS, 2 workgroups per CU) or 64 (K tile 32 bf16,
+// 32 KiB, 4 workgroups per CU: the fill/drain and epilogue of one workgroup hide under three others - short-K GEMMs).
+template <int RBK> __device__ __forceinline__ int kswz(int row, int chunk) {
+  if constexpr (RBK == 128) return row * 128 + ((chunk ^ (row & 7)) << 4);
+  else return row * 64 + ((chunk ^ ((0x78 >> (((row >> 2) & 3) << 1)) & 3)) << 4);   // g = [0,2,3,1]: conflict-free b128 reads
+}
+
+template <typename T, bool TA, bool TB, int RBK>
+__global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(GemmArgs g) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
-  constexpr int BK = RB / sizeof(T);      // k elements per tile (64 bf16 / 32 f32)
-  constexpr int KSTEPS = BK / M_::KS;     // 2
+  constexpr int BK = RBK / sizeof(T);     // k elements per tile (64 or 32 bf16 / 32 or 16 f32)
+  constexpr int KSTEPS = BK / M_::KS;     // 2 or 1
   constexpr int RBT = KMajorFrag<T, 128>::RBT; // bytes per row of a k-major tile (128 elements)
   constexpr int NCT = RBT / 16;           // 16-byte chunks per k-major row
-  constexpr int TILE_BYTES = BM * RB;     // 16 KiB either layout
+  constexpr int TILE_BYTES = BM * RBK;    // 16 or 8 KiB, either layout
+  constexpr int NCK = RBK / 16;           // chunks per k-contiguous row
+  constexpr int PPW = TILE_BYTES / 4096;  // 1-KiB pieces per wave per operand tile (4 or 2)
+  constexpr int RPK = 1024 / RBK;         // k-contiguous rows per piece
   __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
   char* ldsA = lds;                       // [2][TILE_BYTES]
   char* ldsB = lds + 2 * TILE_BYTES;
@@ -198,15 +209,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
   // instruction fills 1 KiB of LDS linearly (wave-uniform base + 16 B * lane); the swizzle is applied by choosing which
   // global chunk each lane fetches.  4 pieces of A and 4 of B per wave per K tile.  Out-of-range chunks (K edge, ragged
   // M/N of a k-major operand) are fetched from a 16-byte zero block instead.
-  const T* a_src[4];
-  const T* b_src[4];
-  bool a_ok[4], b_ok[4];
-  int a_kofs[4], b_kofs[4];
+  const T* a_src[PPW];
+  const T* b_src[PPW];
+  bool a_ok[PPW], b_ok[PPW];
+  int a_kofs[PPW], b_kofs[PPW];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pi = wave * 4 + i;
+  for (int i = 0; i < PPW; ++i) {
+    const int pi = wave * PPW + i;
     if constexpr (!TA) {
-      const int row = 8 * pi + (lane >> 3), c = (lane & 7) ^ (row & 7);
+      const int row = RPK * pi + lane / NCK, c = (kswz<RBK>(row, lane % NCK) - row * RBK) >> 4;
       int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
       a_src[i] = A + (size_t)gr * g.lda + c * EPC;
       a_ok[i] = true; a_kofs[i] = c * EPC;
@@ -217,7 +228,7 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
       a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = row;
     }
     if constexpr (!TB) {
-      const int lr = 8 * pi + (lane >> 3), c = (lane & 7) ^ (lr & 7);
+      const int lr = RPK * pi + lane / NCK, c = (kswz<RBK>(lr, lane % NCK) - lr * RBK) >> 4;
       // LDS row lr holds tile row r (output column n0 + r) with lr = 64*(r/64) + 16*(r%4) + (r%64)/4
       const int r = (lr & 64) + ((lr & 15) << 2) + ((lr >> 4) & 3);
       int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
@@ -233,10 +244,10 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
   using gptr = const __attribute__((address_space(1))) void*;
   using lptr = __attribute__((address_space(3))) void*;
   auto stage = [&](int buf, int k0) {
-    char* la = ldsA + buf * TILE_BYTES + wave * 4096;
-    char* lb = ldsB + buf * TILE_BYTES + wave * 4096;
+    char* la = ldsA + buf * TILE_BYTES + wave * (PPW * 1024);
+    char* lb = ldsB + buf * TILE_BYTES + wave * (PPW * 1024);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < PPW; ++i) {
       const T* pa = (a_ok[i] && (k0 + a_kofs[i]) < kend) ? (TA ? a_src[i] + (size_t)k0 * g.lda : a_src[i] + k0)
                                                           : reinterpret_cast<const T*>(g_zero16);
       const T* pb = (b_ok[i] && (k0 + b_kofs[i]) < kend) ? (TB ? b_src[i] + (size_t)k0 * g.ldb : b_src[i] + k0)
@@ -266,15 +277,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 2) void gemm_kernel(GemmArgs g) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       Frag fa[4], fb[4];
-      const int cbyte = (ks * 4 + lg) * 16;
+      const int cchunk = ks * 4 + lg;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
-        if constexpr (!TA) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
+        if constexpr (!TA) fa[i] = lds_frag<T>(la, kswz<RBK>(wm * 64 + i * 16 + li, cchunk));
         else fa[i] = KMajorFrag<T, 128>::load(la, ks, wm * 64 + i * 16, lane);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        if constexpr (!TB) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
+        if constexpr (!TB) fb[j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, cchunk));
         else fb[j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
       }
 #pragma unroll
@@ -573,6 +584,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
              ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
   const int bk = dtype == kBF16 ? 64 : 32;
   const int tiles = g.tiles_m * g.tiles_n;
+  static const int force_bk = getenv("MISSM_GEMM_BK") ? atoi(getenv("MISSM_GEMM_BK")) : 0;   // tuning knob (32 / 64)
   const int fill = big ? 256 : 512;   // workgroups that fill the chip once (1 resp. 2 per CU)
   if (splitk <= 0) {  // auto: only worth it when the tile grid cannot fill the 256 CUs
     splitk = 1;
@@ -616,7 +628,13 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
     return missm_check_launch("gemm3");
   }
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
-#define MISSM_GEMM_LAUNCH(T, TA, TB) hipLaunchKernelGGL((gemm_kernel<T, TA, TB>), grid, block, 0, s, g)
+  // 32-deep K tiles / 4 workgroups per CU: +3..6 % on the video tower's K = 768 GEMMs (many tiles), -3..20 % on small grids
+  const bool shortk = !trans_a && force_bk != 64 && (force_bk == 32 || (K <= 1024 && tiles >= 1024));
+#define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
+  do {                                                                                                     \
+    if (shortk) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 64>), grid, block, 0, s, g);                     \
+    else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 0, s, g);                           \
+  } while (0)
   if (dtype == kBF16) {
     if (!trans_a && !trans_b) MISSM_GEMM_LAUNCH(bf16, false, false);
     else if (!trans_a && trans_b) MISSM_GEMM_LAUNCH(bf16, false, true);

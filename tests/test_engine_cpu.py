@@ -1,0 +1,110 @@
+"""World-size-2 rehearsal of the data-parallel engine on CPU (gloo): flat-buffer broadcast, gradient all-reduce of every
+tower's flat gradient + the flattened remainder, and the bookkeeping around unused towers.  The arithmetic kernels need
+a GPU, so gradients are synthesised; what is exercised here is exactly the collective logic bench.py runs over RCCL."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _build():
+    sys.path.insert(0, ROOT)
+    import missm_benchmark_amd as M
+    lb, base = M.install()
+    from missm_benchmark_amd.towers import TowerConfig
+    tiny = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=32, patch_size=16)
+    cfgs = {"image": TowerConfig(kind="vision", **tiny), "video": TowerConfig(kind="vision", add_time_attn=True, num_frames=2, **tiny)}
+    tcfg = TowerConfig(kind="text", hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, vocab_size=64,
+                       max_position_embeddings=8)
+    return lb, base, cfgs, tcfg
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lb, base, cfgs, tcfg = _build()
+        from missm_benchmark_amd.engine import TrainEngine
+        enc = lb.LanguageBind({"image": "i", "video": "v"}, configs=cfgs, text_config=tcfg, projection_dim=16, seed=100 + rank)
+        args = types.SimpleNamespace(modality_types=["image", "video"], feature_dims=16, fusion_dim=8, dropout_prob=0.0, fusion_type="sum")
+        model = base.finetune_model(args, 3, enc)
+        before = model.get_parameter("encoder.modality_encoder.image.encoder.layers.0.mlp.fc1.weight").detach().clone()
+        engine = TrainEngine(model, lr=1e-3, overlap=(rank >= 0))
+        after = model.get_parameter("encoder.modality_encoder.image.encoder.layers.0.mlp.fc1.weight").detach().clone()
+        # (1) construction broadcasts rank 0's parameters (DDP constructor semantics)
+        ref = [torch.zeros_like(after) for _ in range(world)]
+        dist.all_gather(ref, after)
+        same_params = all(torch.equal(ref[0], r) for r in ref)
+        changed_on_nonzero = (rank == 0) or (not torch.equal(before, after))
+        # (2) gradient exchange: towers that ran backward are reduced as one flat message each, the rest as one more
+        towers = {name: t for name, t in model.encoder.modality_encoder.items()}
+        for name in ("image", "video"):
+            g = towers[name].flat_grad()
+            g.fill_(float(rank + 1))
+            towers[name]._grad_fresh = True
+            engine._tower_done(towers[name])          # what the tower's backward calls when its last kernel is enqueued
+        engine.rest.grad.fill_(float(10 * (rank + 1)))
+        engine.reduce_gradients()
+        tot = sum(r + 1 for r in range(world))
+        ok_sum = all(float(towers[n].flat_grad().min()) == tot == float(towers[n].flat_grad().max()) for n in ("image", "video"))
+        ok_rest = float(engine.rest.grad.min()) == 10 * tot == float(engine.rest.grad.max())
+        # (3) the text tower did not run: its gradient stays untouched and it is skipped by the optimizer bookkeeping
+        lang = towers["language"]
+        ok_unused = (not lang._grad_fresh) and float(lang.flat_grad().abs().max()) == 0.0
+        # (4) parameter views survive: every registered parameter still aliases its flat buffer
+        views_ok = all(p.data_ptr() >= t.flat_master().data_ptr() and p.data_ptr() < t.flat_master().data_ptr() + 4 * t.flat_master().numel()
+                       for t in towers.values() for p in t.parameters())
+        rest_ok = all(p.grad is not None and p.grad.data_ptr() == v.data_ptr() for p, v in zip(engine.rest.params, engine.rest.views))
+        q.put((rank, same_params, changed_on_nonzero, ok_sum, ok_rest, ok_unused, views_ok, rest_ok, ""))
+    except Exception as e:  # pragma: no cover
+        import traceback
+        q.put((rank, False, False, False, False, False, False, False, traceback.format_exc()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_engine_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 500)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for r in sorted(res):
+        assert r[-1] == "", r[-1]
+        assert all(r[1:-1]), r
+
+
+def test_missing_index_recipe_matches_reference_fixture():
+    """product-side synthetic missing-index generator == reference's simulate_missing_modality (fixture from the reference)"""
+    sys.path.insert(0, ROOT)
+    from conftest import load_golden
+    from missm_benchmark_amd.data import synth_missing_index
+    for case in load_golden("missing_index"):
+        assert torch.equal(synth_missing_index(case["n"], case["modal"], case["ratio"], case["seed"]), case["index"])
+
+
+def test_apply_adam_refuses_cpu():
+    lb, base, cfgs, tcfg = _build()
+    from missm_benchmark_amd.engine import TrainEngine
+    enc = lb.LanguageBind({"image": "i"}, configs=cfgs, text_config=tcfg, projection_dim=16)
+    args = types.SimpleNamespace(modality_types=["image"], feature_dims=16, fusion_dim=8, dropout_prob=0.0, fusion_type="sum")
+    model = base.finetune_model(args, 3, enc)
+    eng = TrainEngine(model)
+    for t in eng.towers:
+        t._grad_fresh = True
+    with pytest.raises(RuntimeError, match="no CPU optimizer path"):
+        eng.apply_adam()
+    from missm_benchmark_amd import _lib
+    with pytest.raises(_lib.MissmError, match="no CPU fallback"):
+        model({"image": {"pixel_values": torch.zeros(1, 3, 32, 32)}}, torch.zeros(1, dtype=torch.int64))
