@@ -44,9 +44,29 @@ def parse():
     ap.add_argument("--modalities", default=",".join(MODALITIES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--serial-streams", action="store_true", help="encode the modalities on one stream (per-kernel timings are then exclusive)")
     return ap.parse_args()
+
+
+def usable_cores() -> int:
+    """cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands out a share of
+    the host; sizing the thread pool by os.cpu_count() would oversubscribe it many times over)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]))))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, q // per))
+        except Exception:
+            pass
+    return max(1, n)
 
 
 def cpu_baseline(modalities, cpu_batch):
@@ -54,7 +74,7 @@ def cpu_baseline(modalities, cpu_batch):
     import torch
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import missm_oracle as O
-    cores = os.cpu_count() or 1
+    cores = usable_cores()
     torch.set_num_threads(cores)
     cfgs, params, proj, scales = {}, {}, {}, {}
     for i, m in enumerate(modalities):
@@ -73,13 +93,17 @@ def cpu_baseline(modalities, cpu_batch):
         logits, _ = O.finetune_forward(data, missing, params, cfgs, proj, scales, fp, modalities)
         O.cross_entropy(logits, labels).backward()
 
-    one()  # warm-up (allocator, thread pool)
+    print(f"[bench] cpu_baseline: oracle fwd+bwd of {cpu_batch} sample(s) on {cores} host threads ...", file=sys.stderr, flush=True)
+    with torch.no_grad():   # warm-up of the thread pool / allocator on the cheapest tower only
+        O.vision_tower(data[modalities[0]]["pixel_values"], params[modalities[0]], cfgs[modalities[0]])
+    print("[bench] cpu_baseline: warm-up done, timing one pass", file=sys.stderr, flush=True)
     t0 = time.perf_counter()
     one()
     dt = time.perf_counter() - t0
-    return {"value": cpu_batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+    print(f"[bench] cpu_baseline: {dt:.1f} s", file=sys.stderr, flush=True)
+    return {"value": round(cpu_batch / dt, 4), "unit": "samples/s", "cores": cores, "kind": "port",
             "sample": f"{cpu_batch} sample(s) x {len(modalities)} modalities, fwd+bwd (no optimizer), fp32 torch CPU oracle, "
-                      f"1 timed pass after 1 warm-up ({dt:.1f} s)"}
+                      f"1 timed pass ({dt:.1f} s) after a 1-tower warm-up"}
 
 
 def main():

@@ -33,6 +33,8 @@ __device__ __forceinline__ size_t seq_base(const AttnArgs& a, int q) {
 }
 
 constexpr int HD = 64;
+constexpr int ANW = 8;            // waves per MFMA-attention workgroup (512 threads): query / key tiles are dealt round-robin
+constexpr int ATHREADS = ANW * 64;
 constexpr float kNegInf = -__builtin_huge_valf();
 
 __device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4];   // source of zero-filled LDS chunks
@@ -48,7 +50,7 @@ __device__ __forceinline__ void stage_head(char* lds, const T* src, size_t base,
   using lptr = __attribute__((address_space(3))) void*;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int npieces = LP / RPP;
-  for (int pi = wave; pi < npieces; pi += 4) {
+  for (int pi = wave; pi < npieces; pi += ANW) {
     const int row = pi * RPP + lane / NC, c = (lane % NC) ^ (row & M);
     const T* p = (row < L) ? src + (base + (size_t)row * tok_stride) * ld + col0 + c * EPC
                            : reinterpret_cast<const T*>(g_attn_zero16);
@@ -61,7 +63,7 @@ __device__ __forceinline__ void stage_wait() {
 }
 
 template <typename T, int NTP>
-__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
@@ -81,21 +83,32 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
 
   stage_head<T, RBv>(ldsK, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, tid);
   stage_head<T, RBv>(ldsV, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
-  for (int k = tid; k < LP; k += 256)
+  for (int k = tid; k < LP; k += ATHREADS)
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
+
+  // Q fragments of every query tile this wave owns are fetched while the K/V pieces are still in flight
+  const int nqt = (L + 15) / 16;
+  constexpr int MAXQ = (NTP + ANW - 1) / ANW;
+  Frag qfa[MAXQ][KSQ];
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int qi = (wave + t * ANW) * 16 + li;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qfa[t][ks] = M_::zero();
+      if (qi < L) qfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + (base + (size_t)qi * a.tok_stride) * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+    }
+  }
   stage_wait();
 
-  const int nqt = (L + 15) / 16;
-  for (int qt = wave; qt < nqt; qt += 4) {
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int qt = wave + t * ANW;
+    if (qt >= nqt) break;
     const int qi = qt * 16 + li;
     const bool qvalid = qi < L;
     const size_t qrow = base + (size_t)(qvalid ? qi : 0) * a.tok_stride;
-    Frag qf[KSQ];
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) {
-      qf[ks] = M_::zero();
-      if (qvalid) qf[ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
-    }
+    Frag (&qf)[KSQ] = qfa[t];
     f32x4 p[NTP];
     float mx = kNegInf;
 #pragma unroll
@@ -143,7 +156,7 @@ __global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(AttnArgs a) {
 }
 
 template <typename T, int NTP>
-__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
@@ -168,28 +181,39 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
 
   stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, tid);
   stage_head<T, RBv>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
-  for (int k = tid; k < LP; k += 256) {
+  for (int k = tid; k < LP; k += ATHREADS) {
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
     lseL[k] = k < L ? lse[k] : __builtin_huge_valf();
     Dl[k] = 0.f;
   }
+  const int nt = (L + 15) / 16;
+  constexpr int MAXQ = (NTP + ANW - 1) / ANW;   // query / key tiles per wave
+  Frag qfa[MAXQ][KSQ], dofa[MAXQ][KSQ];
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int qi = (wave + t * ANW) * 16 + li;
+    const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qfa[t][ks] = M_::zero(); dofa[t][ks] = M_::zero();
+      if (qi < L) {
+        qfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+        dofa[t][ks] = *reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
+      }
+    }
+  }
   stage_wait();
 
   // ---------------- pass A: query on the lane -> dQ, D ----------------
-  const int nt = (L + 15) / 16;
-  for (int qt = wave; qt < nt; qt += 4) {
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int qt = wave + t * ANW;
+    if (qt >= nt) break;
     const int qi = qt * 16 + li;
     const bool qvalid = qi < L;
     const size_t qrow = base + (size_t)(qvalid ? qi : 0) * a.tok_stride;
-    Frag qf[KSQ], dof[KSQ];
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) {
-      qf[ks] = M_::zero(); dof[ks] = M_::zero();
-      if (qvalid) {
-        qf[ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
-        dof[ks] = *reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
-      }
-    }
+    Frag (&qf)[KSQ] = qfa[t];
+    Frag (&dof)[KSQ] = dofa[t];
     const float lq = lseL[qi];
     f32x4 p_[NTP], ds[NTP];
     float dsum = 0.f;
@@ -236,20 +260,30 @@ __global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(AttnArgs a) {
   // ---------------- pass B: key on the lane -> dK, dV ----------------
   stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, tid);
   stage_head<T, RBv>(X1, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, tid);
+  Frag kfa[MAXQ][KSQ], vfa[MAXQ][KSQ];
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int key = (wave + t * ANW) * 16 + li;
+    const size_t krow = base + (size_t)(key < L ? key : 0) * a.tok_stride;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      kfa[t][ks] = M_::zero(); vfa[t][ks] = M_::zero();
+      if (key < L) {
+        kfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+        vfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+      }
+    }
+  }
   stage_wait();
-  for (int kt = wave; kt < nt; kt += 4) {
+#pragma unroll
+  for (int t = 0; t < MAXQ; ++t) {
+    const int kt = wave + t * ANW;
+    if (kt >= nt) break;
     const int key = kt * 16 + li;
     const bool kin = key < L;
     const size_t krow = base + (size_t)(kin ? key : 0) * a.tok_stride;
-    Frag kf[KSQ], vf[KSQ];
-#pragma unroll
-    for (int ks = 0; ks < KSQ; ++ks) {
-      kf[ks] = M_::zero(); vf[ks] = M_::zero();
-      if (kin) {
-        kf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
-        vf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
-      }
-    }
+    Frag (&kf)[KSQ] = kfa[t];
+    Frag (&vf)[KSQ] = vfa[t];
     const float kb = kbias[key];
     f32x4 p_[NTP], ds[NTP];
 #pragma unroll
@@ -512,7 +546,7 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
     return missm_check_launch("attn_small");
   }
   if (hd != HD || L > 256) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64 and L<=256)", L, hd); return MISSM_ERR_INVALID; }
-  dim3 grid(a.nseq * a.H), block(256);
+  dim3 grid(a.nseq * a.H), block(ATHREADS);
 #define MISSM_MFMA(NTP)                                                                                     \
   do {                                                                                                      \
     size_t shmem = (size_t)2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1);              \
