@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--modalities", default=",".join(MODALITIES))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--cpu-batch", type=int, default=2)
+    ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--serial-streams", action="store_true", help="encode the modalities on one stream (per-kernel timings are then exclusive)")
     return ap.parse_args()
 
