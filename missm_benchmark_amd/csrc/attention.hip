@@ -42,27 +42,29 @@ __device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4];   // sour
 // stage L rows (zero-filled up to LP) of one head's [L, 64] slice into a swizzled LDS tile with global_load_lds:
 // every 1-KiB piece is one wave instruction, all pieces of the tile are in flight together (no VGPR round trip);
 // the caller waits with vmcnt(0) + barrier.  LDS position (row, chunk c') holds source chunk c' ^ (row & M).
-template <typename T, int RBv>
+template <typename T, int RBv, int NWV>
 __device__ __forceinline__ void stage_head(char* lds, const T* src, size_t base, int tok_stride, int ld, int col0, int L, int LP,
-                                           int tid) {
+                                           int lane, int wave) {
   constexpr int NC = RBv / 16, EPC = 16 / sizeof(T), RPP = 1024 / RBv, M = (NC - 1) & 7;
   using gptr = const __attribute__((address_space(1))) void*;
   using lptr = __attribute__((address_space(3))) void*;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int npieces = LP / RPP;
-  for (int pi = wave; pi < npieces; pi += ANW) {
+  for (int pi = wave; pi < npieces; pi += NWV) {
     const int row = pi * RPP + lane / NC, c = (lane % NC) ^ (row & M);
     const T* p = (row < L) ? src + (base + (size_t)row * tok_stride) * ld + col0 + c * EPC
                            : reinterpret_cast<const T*>(g_attn_zero16);
     __builtin_amdgcn_global_load_lds((gptr)p, (lptr)(lds + pi * 1024), 16, 0, 0);
   }
 }
-__device__ __forceinline__ void stage_wait() {
+template <bool PW> __device__ __forceinline__ void stage_wait() {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  if constexpr (!PW) __syncthreads();   // per-wave units own their LDS slice: the wave's own vmcnt is the only dependency
 }
 
-template <typename T, int NTP>
+// PW = false: one workgroup (8 waves) per (sequence, head), tiles dealt over the waves  (S = 197 / 77)
+// PW = true : one WAVE per (sequence, head) with its own LDS slice, no workgroup barrier (time attention, L = T <= 32):
+//             the 8x8 score block rides in one 16x16 MFMA tile; 6 MFMAs per unit instead of ~2000 VALU FMAs per lane.
+template <typename T, int NTP, bool PW>
 __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
@@ -70,40 +72,46 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
   constexpr int LP = NTP * 16;
   constexpr int KSQ = HD / M_::KS;            // k-steps over head_dim
   constexpr int NU = NTP / M_::CTILES;        // C-as-operand steps over keys
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  constexpr int SLICE = 2 * LP * RBv + LP * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  char* smem = smem_all + (PW ? wave * SLICE : 0);
   char* ldsK = smem;
   char* ldsV = smem + LP * RBv;
   float* kbias = reinterpret_cast<float*>(smem + 2 * LP * RBv);
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int seq = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int unit = PW ? blockIdx.x * ANW + wave : blockIdx.x;
+  if (PW && unit >= a.nseq * a.H) return;
+  const int seq = unit / a.H, h = unit % a.H;
   const size_t base = seq_base(a, seq);
   const T* qkv = static_cast<const T*>(a.qkv);
   const int L = a.L;
+  constexpr int NWV = PW ? 1 : ANW;           // waves cooperating on one unit
+  const int wv = PW ? 0 : wave;               // this wave's index among them
 
-  stage_head<T, RBv>(ldsK, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, tid);
-  stage_head<T, RBv>(ldsV, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
-  for (int k = tid; k < LP; k += ATHREADS)
+  stage_head<T, RBv, NWV>(ldsK, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wv);
+  stage_head<T, RBv, NWV>(ldsV, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, lane, wv);
+  for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS)
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
 
   // Q fragments of every query tile this wave owns are fetched while the K/V pieces are still in flight
   const int nqt = (L + 15) / 16;
-  constexpr int MAXQ = (NTP + ANW - 1) / ANW;
+  constexpr int MAXQ = (NTP + NWV - 1) / NWV;
   Frag qfa[MAXQ][KSQ];
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int qi = (wave + t * ANW) * 16 + li;
+    const int qi = (wv + t * NWV) * 16 + li;
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
       qfa[t][ks] = M_::zero();
       if (qi < L) qfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + (base + (size_t)qi * a.tok_stride) * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
     }
   }
-  stage_wait();
+  stage_wait<PW>();
 
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int qt = wave + t * ANW;
+    const int qt = wv + t * NWV;
     if (qt >= nqt) break;
     const int qi = qt * 16 + li;
     const bool qvalid = qi < L;
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
   }
 }
 
-template <typename T, int NTP>
+template <typename T, int NTP, bool PW>
 __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
@@ -163,15 +171,21 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
   constexpr int LP = NTP * 16;
   constexpr int KSQ = HD / M_::KS;
   constexpr int NU = NTP / M_::CTILES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  constexpr int SLICE = 2 * LP * RBv + 3 * LP * 4;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  char* smem = smem_all + (PW ? wave * SLICE : 0);
   char* X0 = smem;                 // pass A: K   ; pass B: Q
   char* X1 = smem + LP * RBv;      // pass A: V   ; pass B: dO
   float* kbias = reinterpret_cast<float*>(smem + 2 * LP * RBv);
   float* lseL = kbias + LP;
   float* Dl = lseL + LP;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
-  const int seq = blockIdx.x / a.H, h = blockIdx.x % a.H;
+  const int unit = PW ? blockIdx.x * ANW + wave : blockIdx.x;
+  if (PW && unit >= a.nseq * a.H) return;
+  const int seq = unit / a.H, h = unit % a.H;
+  constexpr int NWV = PW ? 1 : ANW;
+  const int wv = PW ? 0 : wave;
   const size_t base = seq_base(a, seq);
   const T* qkv = static_cast<const T*>(a.qkv);
   const T* dout = static_cast<const T*>(a.dout);
@@ -179,19 +193,19 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
   const int L = a.L;
   const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
 
-  stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, tid);
-  stage_head<T, RBv>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, tid);
-  for (int k = tid; k < LP; k += ATHREADS) {
+  stage_head<T, RBv, NWV>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wv);
+  stage_head<T, RBv, NWV>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, lane, wv);
+  for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS) {
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
     lseL[k] = k < L ? lse[k] : __builtin_huge_valf();
     Dl[k] = 0.f;
   }
   const int nt = (L + 15) / 16;
-  constexpr int MAXQ = (NTP + ANW - 1) / ANW;   // query / key tiles per wave
+  constexpr int MAXQ = (NTP + NWV - 1) / NWV;   // query / key tiles per wave
   Frag qfa[MAXQ][KSQ], dofa[MAXQ][KSQ];
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int qi = (wave + t * ANW) * 16 + li;
+    const int qi = (wv + t * NWV) * 16 + li;
     const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
@@ -202,12 +216,12 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
       }
     }
   }
-  stage_wait();
+  stage_wait<PW>();
 
   // ---------------- pass A: query on the lane -> dQ, D ----------------
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int qt = wave + t * ANW;
+    const int qt = wv + t * NWV;
     if (qt >= nt) break;
     const int qi = qt * 16 + li;
     const bool qvalid = qi < L;
@@ -255,15 +269,16 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
       if (qvalid) store4(dqkv + qrow * a.ld + h * HD + dt * 16 + 4 * lg, acc);
     }
   }
-  __syncthreads();
+  if constexpr (!PW) __syncthreads();
+  else asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 
   // ---------------- pass B: key on the lane -> dK, dV ----------------
-  stage_head<T, RBv>(X0, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, tid);
-  stage_head<T, RBv>(X1, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, tid);
+  stage_head<T, RBv, NWV>(X0, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, lane, wv);
+  stage_head<T, RBv, NWV>(X1, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, lane, wv);
   Frag kfa[MAXQ][KSQ], vfa[MAXQ][KSQ];
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int key = (wave + t * ANW) * 16 + li;
+    const int key = (wv + t * NWV) * 16 + li;
     const size_t krow = base + (size_t)(key < L ? key : 0) * a.tok_stride;
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
@@ -274,10 +289,10 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
       }
     }
   }
-  stage_wait();
+  stage_wait<PW>();
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
-    const int kt = wave + t * ANW;
+    const int kt = wv + t * NWV;
     if (kt >= nt) break;
     const int key = kt * 16 + li;
     const bool kin = key < L;
@@ -530,6 +545,16 @@ int fill_args(AttnArgs& a, const void* qkv, void* out, float* lse, const void* d
 
 template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipStream_t s) {
   const int L = a.L;
+  if (L <= 32 && hd == HD) {   // time attention / short text: one wave per (sequence, head) on the MFMA path
+    constexpr int NTP = 2;
+    const int units = a.nseq * a.H;
+    dim3 grid((units + ANW - 1) / ANW), block(ATHREADS);
+    size_t shmem = (size_t)ANW * (2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1));
+    auto k = BWD ? attn_bwd_mfma_kernel<T, NTP, true> : attn_fwd_mfma_kernel<T, NTP, true>;
+    int rc = launch_dyn(k, grid, block, shmem, s, "attn_wave"); if (rc) return rc;
+    hipLaunchKernelGGL(k, grid, block, shmem, s, a);
+    return missm_check_launch("attn_wave");
+  }
   if (L <= 32) {
     const int PW = 64 / L;
     const int total = a.nseq * a.H;
@@ -550,7 +575,7 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
 #define MISSM_MFMA(NTP)                                                                                     \
   do {                                                                                                      \
     size_t shmem = (size_t)2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1);              \
-    auto k = BWD ? attn_bwd_mfma_kernel<T, NTP> : attn_fwd_mfma_kernel<T, NTP>;                                \
+    auto k = BWD ? attn_bwd_mfma_kernel<T, NTP, false> : attn_fwd_mfma_kernel<T, NTP, false>;                  \
     int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                            \
     hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                         \
   } while (0)
