@@ -55,7 +55,7 @@ class FlatGroup:
 
 class TrainEngine:
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 process_group=None, overlap: bool = True):
+                 process_group=None, overlap: bool = True, eager_step: bool = True):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pg = process_group
@@ -68,9 +68,14 @@ class TrainEngine:
         self._state = {}
         self._pending = []
         self.overlap = overlap and self.world > 1
+        # eager_step: a tower's Adam update (and the refresh of its bf16 weight copies) is enqueued as soon as its gradient
+        # is final - right behind its backward (1 GPU) or behind its all-reduce on the communication stream (N GPUs) -
+        # instead of serialising every optimizer launch after the whole backward.  One backward per step is assumed.
+        self.eager_step = eager_step
+        self._eager_done = set()
         self.comm_stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
         for t in self.towers:
-            t._post_backward = self._tower_done if self.world > 1 else None
+            t._post_backward = self._tower_done if (self.world > 1 or eager_step) else None
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -102,8 +107,22 @@ class TrainEngine:
         self._pending.append(h)
 
     def _tower_done(self, tower: ClipTower):
-        if self.overlap:
+        """called by the tower's backward on the stream it ran on, after its last kernel was enqueued"""
+        if self.world > 1:
+            if not self.overlap:
+                return
             self._all_reduce_async(tower.flat_grad())
+            if self.eager_step and tower.flat_master().is_cuda:
+                h = self._pending.pop()
+                with torch.cuda.stream(self.comm_stream):
+                    h.wait()                      # comm stream waits for the reduction, then updates this tower
+                    self._adam_on(tower.flat_master(), tower.flat_grad(), tower)
+                    tower._ensure_ready()
+                self._eager_done.add(id(tower))
+        elif self.eager_step and tower.flat_master().is_cuda:
+            self._adam_on(tower.flat_master(), tower.flat_grad(), tower)
+            tower._ensure_ready()                 # re-derive the compute-dtype weight copies behind the update
+            self._eager_done.add(id(tower))
 
     def zero_grad(self):
         if self.rest is not None:
@@ -128,23 +147,28 @@ class TrainEngine:
         elif self.rest is not None:
             self.rest.reattach()
 
+    def _adam_on(self, master, grad, t):
+        if not master.is_cuda:
+            raise RuntimeError("TrainEngine.apply_adam: parameters are not on a GPU (no CPU optimizer path)")
+        key = master.data_ptr()
+        if key not in self._state:
+            self._state[key] = (torch.zeros_like(master), torch.zeros_like(master))
+        m, v = self._state[key]
+        ops.adam_step(master, grad, m, v, self.step_count + 1, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                      grad_scale=1.0 / self.world)
+        if t is not None:
+            t.mark_dirty()
+            t._grad_fresh = False
+
     def apply_adam(self):
-        """one fused Adam launch per flat buffer; the 1/world mean of the SUM all-reduce is folded in"""
-        self.step_count += 1
+        """one fused Adam launch per flat buffer (towers already updated eagerly are skipped); the 1/world mean of the SUM
+        all-reduce is folded in"""
         for master, grad, t in self.flat_buffers():
-            if t is not None and not t._grad_fresh:
-                continue   # tower not used this step (e.g. no 'language' input): its gradient is None in the reference too
-            if not master.is_cuda:
-                raise RuntimeError("TrainEngine.apply_adam: parameters are not on a GPU (no CPU optimizer path)")
-            key = master.data_ptr()
-            if key not in self._state:
-                self._state[key] = (torch.zeros_like(master), torch.zeros_like(master))
-            m, v = self._state[key]
-            ops.adam_step(master, grad, m, v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                          grad_scale=1.0 / self.world)
-            if t is not None:
-                t.mark_dirty()
-                t._grad_fresh = False
+            if t is not None and (id(t) in self._eager_done or not t._grad_fresh):
+                continue   # updated eagerly, or not used this step (e.g. no 'language' input: gradient None in the reference)
+            self._adam_on(master, grad, t)
+        self._eager_done.clear()
+        self.step_count += 1
 
     def step(self):
         self.reduce_gradients()
