@@ -114,10 +114,12 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs an MI355X (there is no CPU product path)"
-    torch.cuda.set_device(local)
+    torch.cuda.set_device(local if local < torch.cuda.device_count() else 0)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", init_method="env://")
+        # "nccl" is RCCL on ROCm.  MISSM_DIST_BACKEND=gloo lets the N > 1 engine path be rehearsed with several ranks on ONE GPU
+        # (RCCL refuses two ranks on one device); ranks then share device 0.
+        dist.init_process_group(os.environ.get("MISSM_DIST_BACKEND", "nccl"), init_method="env://")
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     import missm_benchmark_amd as M

@@ -73,6 +73,7 @@ class TrainEngine:
         # instead of serialising every optimizer launch after the whole backward.  One backward per step is assumed.
         self.eager_step = eager_step
         self._eager_done = set()
+        self._host_sync_before_collective = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
         self.comm_stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
         for t in self.towers:
             t._post_backward = self._tower_done if (self.world > 1 or eager_step) else None
@@ -98,6 +99,8 @@ class TrainEngine:
 
     # ---- gradient exchange ------------------------------------------------------------------------
     def _all_reduce_async(self, grad: torch.Tensor):
+        if self._host_sync_before_collective and grad.is_cuda:
+            torch.cuda.current_stream().synchronize()   # gloo rehearsal only: its CUDA path is not stream-ordered like RCCL's
         if self.comm_stream is not None:
             self.comm_stream.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.comm_stream):

@@ -1,0 +1,108 @@
+"""Data-parallel engine on the GPU: 2 ranks (gloo, both on device 0 - RCCL refuses two ranks on one device) must
+(a) stay bit-identical to each other and (b) match one process training on the concatenated batch (1e-4)."""
+import os
+import sys
+import types
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _model(seed=0):
+    torch.manual_seed(1000 + seed)   # the fusion head draws from torch's global RNG (like the reference's nn.Linear init)
+    sys.path.insert(0, ROOT)
+    import missm_benchmark_amd as M
+    lb, base = M.install()
+    from missm_benchmark_amd.towers import TowerConfig
+    tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16)
+    cfgs = {"image": TowerConfig(kind="vision", **tiny), "video": TowerConfig(kind="vision", add_time_attn=True, num_frames=4, **tiny)}
+    tcfg = TowerConfig(kind="text", hidden_size=64, intermediate_size=128, num_hidden_layers=1, num_attention_heads=2, vocab_size=64,
+                       max_position_embeddings=8)
+    enc = lb.LanguageBind({"image": "i", "video": "v"}, configs=cfgs, text_config=tcfg, projection_dim=32, compute_dtype=torch.float32,
+                          seed=seed)
+    args = types.SimpleNamespace(modality_types=["image", "video"], feature_dims=32, fusion_dim=16, dropout_prob=0.0, fusion_type="sum")
+    return base.finetune_model(args, 3, enc)
+
+
+def _batch(rank, B=4):
+    g = torch.Generator().manual_seed(50 + rank)
+    data = {"image": {"pixel_values": torch.randn(B, 3, 32, 32, generator=g)},
+            "video": {"pixel_values": torch.randn(B, 3, 4, 32, 32, generator=g)}}
+    missing = torch.tensor([0, 4, 2, 0])[:B]
+    labels = torch.randint(0, 3, (B,), generator=g)
+    return data, missing, labels
+
+
+KEYS = ["encoder.modality_encoder.video.encoder.layers.0.temporal_attn.q_proj.weight",
+        "encoder.modality_encoder.image.encoder.layers.1.mlp.fc2.weight", "encoder.modality_proj.image.weight",
+        "fusion.head.head.3.weight", "encoder.modality_encoder.video.embeddings.position_embedding.weight"]
+
+
+def _train(model, batches, steps=2, lr=1e-3):
+    """returns (mean gradients of the first step as the optimizer sees them, parameters after `steps` steps)"""
+    from missm_benchmark_amd.engine import TrainEngine
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    eng = TrainEngine(model, lr=lr, eager_step=False)
+    crit = HipCrossEntropyLoss()
+    grads = None
+    for it in range(steps):
+        data, missing, labels = batches
+        eng.zero_grad()
+        loss = crit(model({m: {k: v.cuda() for k, v in d.items()} for m, d in data.items()}, missing.cuda()), labels.cuda())
+        loss.backward()
+        eng.reduce_gradients()
+        if it == 0:
+            torch.cuda.synchronize()
+            grads = {k: (model.get_parameter(k).grad.detach() / eng.world).cpu().clone() for k in KEYS}
+        eng.apply_adam()
+    torch.cuda.synchronize()
+    return grads, {k: model.get_parameter(k).detach().cpu().clone() for k in KEYS}
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        model = _model(seed=7 * (rank + 1)).cuda()          # different init per rank: the engine must broadcast rank 0's
+        out = _train(model, _batch(rank))
+        q.put((rank, out, ""))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_two_ranks_match_single_process_on_concatenated_batch():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29600 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[2] == "", r[2]
+    for k in KEYS:
+        assert torch.equal(res[0][1][1][k], res[1][1][1][k]), f"ranks diverged on {k}"
+        assert torch.equal(res[0][1][0][k], res[1][1][0][k]), f"reduced gradients differ on {k}"
+    # single process, global batch = both ranks' samples (mean loss over 8 = mean of the two per-rank means):
+    # the all-reduced mean gradient must equal the single-process gradient (Adam's sign-like first steps would amplify
+    # rounding noise on near-zero gradients, so gradients - not parameters - are compared)
+    d0, m0, l0 = _batch(0)
+    d1, m1, l1 = _batch(1)
+    data = {m: {"pixel_values": torch.cat([d0[m]["pixel_values"], d1[m]["pixel_values"]])} for m in d0}
+    sgrads, _ = _train(_model(seed=7).cuda(), (data, torch.cat([m0, m1]), torch.cat([l0, l1])), steps=1)
+    for k, v in sgrads.items():
+        err = float((v - res[0][1][0][k]).abs().max() / v.abs().max())
+        assert err < 1e-4, (k, err)
