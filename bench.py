@@ -49,6 +49,18 @@ def parse():
     return ap.parse_args()
 
 
+def workload_name(modalities, args) -> str:
+    ms = set(modalities)
+    if ms == set(MODALITIES):
+        return "configs[3]: 5-modality with %d%% missing-modality codes" % round(args.missing * 100) if args.missing > 0 else \
+               "configs[2]: 5-modality (video T=8/image/audio/depth/thermal)"
+    if ms == {"language", "image"}:
+        return "configs[1]: image + text two-modality fusion"
+    if ms == {"video"}:
+        return "configs[4]: video tower (8 frames x 197 tokens, factorised time attention)"
+    return "custom: " + "+".join(modalities)
+
+
 def usable_cores() -> int:
     """cores this process may actually use: affinity mask capped by the cgroup CPU quota (a GPU box hands out a share of
     the host; sizing the thread pool by os.cpu_count() would oversubscribe it many times over)"""
@@ -129,7 +141,7 @@ def main():
     lb, base = M.install()
     modalities = args.modalities.split(",")
     cdt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    clip_type = {m: f"LanguageBind_{m.capitalize()}" for m in modalities}
+    clip_type = {m: f"LanguageBind_{m.capitalize()}" for m in modalities if m != "language"}
     enc = lb.LanguageBind(clip_type, compute_dtype=cdt, seed=0)
     enc.parallel_streams = not args.serial_streams
     margs = types.SimpleNamespace(modality_types=modalities, feature_dims=768, fusion_dim=256, dropout_prob=0.1, fusion_type="sum")
@@ -141,6 +153,11 @@ def main():
     g = torch.Generator().manual_seed(1 + rank)
     data = {}
     for m in modalities:
+        if m == "language":
+            from missm_benchmark_amd.data import synth_text_batch
+            ids, mask = synth_text_batch(B, 77, seed=100 + rank)
+            data[m] = {"input_ids": ids.cuda(), "attention_mask": mask.cuda()}
+            continue
         shape = (B, 3, 8, 224, 224) if m == "video" else (B, 3, 224, 224)
         data[m] = {"pixel_values": torch.randn(*shape, generator=g).cuda()}
     labels = torch.randint(0, 8, (B,), generator=g).cuda()
@@ -202,7 +219,7 @@ def main():
         flops = sum(f for _, _, f in prof)
         ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": "gemm_nt_kernel<bf16>" if args.dtype == "bf16" else "gemm_nt_kernel<float>", "bound": "mfma",
+        roof = {"kernel": "gemm_kernel<bf16,*> + gemm3_kernel<bf16,*> (MFMA GEMM family)" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                 "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
                 "launches": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),
@@ -214,12 +231,11 @@ def main():
                "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(dt / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "configs[2]: 5-modality (video T=8/image/audio/depth/thermal) ViT-B/16 towers + sum fusion, "
-                                      "fwd+bwd+allreduce+Adam", "per_gpu_batch": B, "global_batch": B * world,
+               "config": {"workload": workload_name(modalities, args) + ": ViT-B/16 towers + sum fusion, fwd+bwd+allreduce+Adam", "per_gpu_batch": B, "global_batch": B * world,
                           "modalities": modalities, "missing_ratio": args.missing, "params": engine.num_parameters(),
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and "language" not in modalities:
             out["cpu_baseline"] = cpu_baseline(modalities, args.cpu_batch)
         print(json.dumps(out), flush=True)
     if world > 1:

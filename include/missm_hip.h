@@ -58,10 +58,11 @@ int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, in
  *   trans_b == 0: B is [N,K] (k contiguous)      trans_b == 1: B is [K,N] (e.g. the weight itself for dX = dY W)
  * so weight and input gradients read activations / weights where they lie - no transposed copies.  (trans_a, trans_b) in
  * {(0,0), (0,1), (1,1)}.  splitk: 1 = off, 0 = auto, > 1 = number of K slices whose partial products are atomically added
- * into a ZERO-INITIALISED fp32 C (weight gradients: tiny output, huge K). */
+ * into a ZERO-INITIALISED fp32 C (weight gradients: tiny output, huge K).  colsum_a (trans_a only, optional): colsum_a[m] +=
+ * sum_k A[k][m] - the bias gradient rides in the weight-gradient GEMM as a ones-column (caller zeroes it). */
 int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b,
                float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act,
-               int out_f32, int accumulate, int splitk, int dtype, void* stream);
+               int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream);
 
 /* out[C, ldo] = in[R, C]^T zero-padded to ldo columns; optional colsum[C] += column sums (bias gradient). */
 int missm_transpose_pad(const void* in, void* out, int R, int C, int ld, int ldo, float* colsum, int dtype, void* stream);

@@ -15,7 +15,7 @@ P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_ulonglong
 # name -> argtypes, exactly mirroring include/missm_hip.h (tests check the export list against the header)
 SIGNATURES = {
     "missm_gemm_nt": [P, P, P, I, I, I, I, I, I, F, P, P, P, P, I, I, I, I, I, P],
-    "missm_gemm": [P, P, P, I, I, I, I, I, I, I, I, F, P, P, P, P, I, I, I, I, I, I, P],
+    "missm_gemm": [P, P, P, I, I, I, I, I, I, I, I, F, P, P, P, P, I, I, I, I, I, P, I, P],
     "missm_transpose_pad": [P, P, I, I, I, I, P, I, P],
     "missm_colsum": [P, P, I, I, I, I, I, I, P],
     "missm_cast_weight": [P, P, P, I, I, I, P],

@@ -35,6 +35,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vec_ok;             // ldc/ldaux/pointers allow 16-byte (fp32) / 8-byte (bf16) vector epilogue accesses
   int splitk, k_per_split;  // splitk > 1: each K slice atomically adds its partial into the (zeroed) fp32 C
+  float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];   // source of zero-filled LDS chunks
@@ -263,6 +264,15 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+  // bias gradient: for the first column of tiles, waves with wn == 0 also multiply their A fragments by a ones-column
+  const bool do_cs = TA && g.colsum_a != nullptr && tn == 0 && wn == 0;
+  Frag ones;
+#pragma unroll
+  for (int j = 0; j < M_::KPL; ++j) ones[j] = from_f32<T>(1.0f);
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk <= 0) return;
   stage(0, kbeg);
@@ -292,9 +302,26 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
+      if constexpr (TA) {
+        if (do_cs) {
+#pragma unroll
+          for (int i = 0; i < 4; ++i) accb[i] = M_::step(fa[i], ones, accb[i]);
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  }
+  if constexpr (TA) {
+    if (do_cs && li == 0) {   // every column of accb holds the row sums; lanes with li == 0 publish rows 4*lg + r
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
+          if (m < g.M) atomicAdd(g.colsum_a + m, accb[i][r]);
+        }
+    }
   }
 
   gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
@@ -692,8 +719,9 @@ using namespace missm;
 
 extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                           int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
-                          int ldaux, int act, int out_f32, int accumulate, int splitk, int dtype, void* stream) {
+                          int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream) {
   MISSM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
+  MISSM_CHECK_ARG(!colsum_a || trans_a, "gemm: colsum_a rides only in the A^T (weight-gradient) form");
   MISSM_CHECK_ARG(dtype == kBF16 || dtype == kF32, "gemm: dtype must be 0 (f32) or 1 (bf16)");
   const int epc = dtype == kBF16 ? 8 : 4;
   MISSM_CHECK_ARG(lda % epc == 0 && ldb % epc == 0, "gemm: lda, ldb must be multiples of 16 bytes");
@@ -706,7 +734,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
-  g.out_f32 = out_f32; g.accumulate = accumulate;
+  g.out_f32 = out_f32; g.accumulate = accumulate; g.colsum_a = colsum_a;
   static const int force_kernel = getenv("MISSM_GEMM_KERNEL") ? atoi(getenv("MISSM_GEMM_KERNEL")) : 0;   // tuning knob: 1 / 3 / 4
   // 256x256 / 4-stage kernel: the grid must still cover the 256 CUs several times at one workgroup per CU
   const int t4 = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
@@ -719,6 +747,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   if (force_kernel == 1) { huge = false; big = false; }
   if (force_kernel == 3) { huge = false; big = M >= 256; }
   if (force_kernel == 4) { huge = M >= 256 && N >= 256; big = false; }
+  if (colsum_a) { huge = false; big = false; }   // the ones-column lives in the 128x128 kernel only
   const int bm = huge ? G4_BM : (big ? G3_BM : BM);
   const int bn = huge ? G4_BN : BN;
   g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + bn - 1) / bn;
@@ -819,7 +848,7 @@ extern "C" int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N
                              const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act,
                              int out_f32, int accumulate, int dtype, void* stream) {
   return missm_gemm(A, B, C, M, N, K, lda, ldb, ldc, 0, 0, alpha, bias, resid, aux_in, aux_out, ldaux, act, out_f32, accumulate, 1,
-                    dtype, stream);
+                    nullptr, dtype, stream);
 }
 
 extern "C" int missm_transpose_pad(const void* in, void* out, int R, int C, int ld, int ldo, float* colsum, int dtype,

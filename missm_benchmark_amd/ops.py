@@ -49,7 +49,7 @@ GEMM_PROFILE = None  # bench.py sets this to a list: (start_event, end_event, fl
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, bias=None,
          resid=None, aux_in=None, aux_out=None, act: int = ACT_NONE, alpha: float = 1.0, accumulate: bool = False,
-         splitk: int = 1, M=None, N=None, K=None):
+         splitk: int = 1, colsum_a=None, M=None, N=None, K=None):
     """out[M,N] = alpha * op(a) @ op(b) (+bias) -> act (+resid).
     a is [M,K] (or [K,M] with trans_a); b is [N,K] (or [K,N] with trans_b); out is the operand dtype or fp32.
     splitk: 1 off, 0 auto, >1 slices (needs a zeroed fp32 ``out``)."""
@@ -78,7 +78,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
         e0.record()
     _lib.call("missm_gemm", a.data_ptr(), b.data_ptr(), out.data_ptr(), M, N, K, a.stride(0), b.stride(0), out.stride(0),
               int(trans_a), int(trans_b), float(alpha), _p(bias), _p(resid), _p(aux_in), _p(aux_out), ldaux, act, out_f32,
-              int(accumulate), int(splitk), dt(a), _s())
+              int(accumulate), int(splitk), _p(colsum_a), dt(a), _s())
     if prof is not None:
         e1.record()
         prof.append((e0, e1, 2.0 * M * N * K))

@@ -113,8 +113,10 @@ def test_gemm_layouts_and_splitk(ops, dtype, M, N, K):
     if N % 8 == 0 and K % 8 == 0:
         for sk in (1, 0, 3):
             dw = torch.zeros(N, K, device="cuda")
-            ops.gemm(dev(dy, dtype), dev(x, dtype), dw, trans_a=True, trans_b=True, splitk=sk)
+            db = torch.zeros(N, device="cuda")
+            ops.gemm(dev(dy, dtype), dev(x, dtype), dw, trans_a=True, trans_b=True, splitk=sk, colsum_a=db)
             assert rel(dw, dy.t() @ x) < TOL[dtype], sk
+            assert rel(db, dy.sum(0)) < TOL[dtype], sk      # bias gradient as a ones-column of the same GEMM
     # NT with split-K
     b = q(rnd(N, K, seed=9), dtype)
     o32 = torch.zeros(M, N, device="cuda")
