@@ -75,93 +75,135 @@ template <int COLS> struct KMajorFrag<float, COLS> {
 // Epilogue of one wave's 64x64 accumulator block whose top-left element is (mw, nw).
 // !TB: lane owns rows 4*lg + r of each 16-row tile i and the 4 CONSECUTIVE columns 4*li + j  (vector accesses)
 //  TB: lane owns column 16*j + li of each n-tile j                                          (scalar accesses)
+// Code size matters here: the epilogue runs once per tile but a 12-K-tile GEMM spends a third of its time around it, and
+// a fully unrolled nest of run-time `act` branches was ~15k instructions (instruction-cache misses on every tile).
+// So: ONE run-time switch, then a tight unrolled store loop per case; everything unusual takes the rolled generic path.
+template <typename T>
+__device__ __forceinline__ void epi_finish(const GemmArgs& g, float x, size_t off, size_t aoff) {
+  if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
+    if (g.aux_out) static_cast<T*>(g.aux_out)[aoff] = from_f32<T>(x);
+    x = (g.act == MISSM_ACT_QGELU) ? quick_gelu(x) : gelu_erf(x);
+  } else if (g.act == MISSM_ACT_DQGELU || g.act == MISSM_ACT_DGELU) {
+    const float u = to_f32(static_cast<const T*>(g.aux_in)[aoff]);
+    x *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u) : gelu_erf_grad(u);
+  } else if (g.act == MISSM_ACT_RELU) {
+    x = fmaxf(x, 0.f);
+  }
+  if (g.out_f32) {
+    float* c = static_cast<float*>(g.C) + off;
+    if (g.splitk > 1) { atomicAdd(c, x); return; }
+    if (g.resid) x += g.resid[off];
+    if (g.accumulate) x += *c;
+    *c = x;
+  } else {
+    static_cast<T*>(g.C)[off] = from_f32<T>(x);
+  }
+}
+
 template <typename T, bool TB>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane) {
   const int li = lane & 15, lg = lane >> 4;
   const bool first_split = split == 0;
-  auto finish = [&](float x, size_t off, size_t aoff) -> void {   // scalar tail of the epilogue for one element
-    if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
-      if (g.aux_out) static_cast<T*>(g.aux_out)[aoff] = from_f32<T>(x);
-      x = (g.act == MISSM_ACT_QGELU) ? quick_gelu(x) : gelu_erf(x);
-    } else if (g.act == MISSM_ACT_DQGELU || g.act == MISSM_ACT_DGELU) {
-      const float u = to_f32(static_cast<const T*>(g.aux_in)[aoff]);
-      x *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u) : gelu_erf_grad(u);
-    } else if (g.act == MISSM_ACT_RELU) {
-      x = fmaxf(x, 0.f);
-    }
-    if (g.out_f32) {
-      float* c = static_cast<float*>(g.C) + off;
-      if (g.splitk > 1) { atomicAdd(c, x); return; }
-      if (g.resid) x += g.resid[off];
-      if (g.accumulate) x += *c;
-      *c = x;
-    } else {
-      static_cast<T*>(g.C)[off] = from_f32<T>(x);
-    }
-  };
-
   if constexpr (TB) {
+    // (register arrays must only ever be indexed with compile-time constants: a rolled loop here sends `acc` to scratch)
+    const bool atomic = g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
+    const bool plain_t = !g.out_f32 && g.act == MISSM_ACT_NONE;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = nw + j * 16 + li;
       if (col >= g.N) continue;
       const float bv = (g.bias && first_split) ? g.bias[col] : 0.f;
+      if (atomic) {                       // weight gradients: split-K partials
+        float* C = static_cast<float*>(g.C);
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = mw + i * 16 + lg * 4 + r;
-          if (row < g.M) finish(acc[i][j][r] * g.alpha + bv, (size_t)row * g.ldc + col, (size_t)row * g.ldaux + col);
-        }
+          for (int r = 0; r < 4; ++r) {
+            const int row = mw + i * 16 + lg * 4 + r;
+            if (row < g.M) atomicAdd(C + (size_t)row * g.ldc + col, acc[i][j][r] * g.alpha + bv);
+          }
+      } else if (plain_t) {
+        T* C = static_cast<T*>(g.C);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mw + i * 16 + lg * 4 + r;
+            if (row < g.M) C[(size_t)row * g.ldc + col] = from_f32<T>(acc[i][j][r] * g.alpha + bv);
+          }
+      } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = mw + i * 16 + lg * 4 + r;
+            if (row < g.M) epi_finish<T>(g, acc[i][j][r] * g.alpha + bv, (size_t)row * g.ldc + col, (size_t)row * g.ldaux + col);
+          }
+      }
     }
+    return;
   } else {
     const int col = nw + li * 4;
     if (col >= g.N) return;
-    const bool full4 = (col + 3 < g.N) && g.vec_ok && g.splitk == 1;
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
     if (g.bias && first_split) {
       if (col + 3 < g.N) bias4 = load4(g.bias + col);
       else
         for (int j = 0; j < 4; ++j) if (col + j < g.N) bias4[j] = g.bias[col + j];
     }
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = mw + i * 16 + lg * 4 + r;
-        if (row >= g.M) continue;
-        f32x4 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = acc[i][j][r] * g.alpha + bias4[j];
-        const size_t off = (size_t)row * g.ldc + col;
-        const size_t aoff = (size_t)row * g.ldaux + col;
-        if (full4) {
-          if (g.act == MISSM_ACT_QGELU || g.act == MISSM_ACT_GELU) {
-            if (g.aux_out) store4(static_cast<T*>(g.aux_out) + aoff, v);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (g.act == MISSM_ACT_QGELU) ? quick_gelu(v[j]) : gelu_erf(v[j]);
-          } else if (g.act == MISSM_ACT_DQGELU || g.act == MISSM_ACT_DGELU) {
-            f32x4 u = load4(static_cast<const T*>(g.aux_in) + aoff);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= (g.act == MISSM_ACT_DQGELU) ? quick_gelu_grad(u[j]) : gelu_erf_grad(u[j]);
-          } else if (g.act == MISSM_ACT_RELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
-          }
-          if (g.out_f32) {
-            float* c = static_cast<float*>(g.C) + off;
-            if (g.resid) { f32x4 q = load4(g.resid + off); v += q; }
-            if (g.accumulate) { f32x4 q = load4(c); v += q; }
-            store4(c, v);
-          } else {
-            store4(static_cast<T*>(g.C) + off, v);
-          }
-        } else {
-          for (int j = 0; j < 4; ++j)
-            if (col + j < g.N) finish(v[j], off + j, aoff + j);
-        }
-      }
+    const float alpha = g.alpha;
+    const bool vec = (col + 3 < g.N) && g.vec_ok && g.splitk == 1 && g.act != MISSM_ACT_RELU && g.act != MISSM_ACT_GELU &&
+                     g.act != MISSM_ACT_DGELU && !g.accumulate;
+    const bool vec_atomic = (col + 3 < g.N) && g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
+    // value of (tile i, register r): 4 consecutive columns
+#define MISSM_EPI_LOOP(BODY)                                                      \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
+      _Pragma("unroll") for (int r = 0; r < 4; ++r) {                             \
+        const int row = mw + i * 16 + lg * 4 + r;                                 \
+        if (row < g.M) {                                                          \
+          f32x4 v = {acc[i][0][r] * alpha + bias4[0], acc[i][1][r] * alpha + bias4[1], acc[i][2][r] * alpha + bias4[2], \
+                     acc[i][3][r] * alpha + bias4[3]};                            \
+          const size_t off = (size_t)row * g.ldc + col;                           \
+          BODY                                                                    \
+        }                                                                         \
+      }                                                                           \
     }
+    if (vec && !g.out_f32 && g.act == MISSM_ACT_NONE) {                 // T store (+bias): QKV projection, dX
+      T* C = static_cast<T*>(g.C);
+      MISSM_EPI_LOOP(store4(C + off, v);)
+    } else if (vec && !g.out_f32 && g.act == MISSM_ACT_QGELU) {         // fc1: activation + saved pre-activation
+      T* C = static_cast<T*>(g.C);
+      T* U = static_cast<T*>(g.aux_out);
+      MISSM_EPI_LOOP(if (U) store4(U + (size_t)row * g.ldaux + col, v);
+                     v[0] = quick_gelu(v[0]); v[1] = quick_gelu(v[1]); v[2] = quick_gelu(v[2]); v[3] = quick_gelu(v[3]);
+                     store4(C + off, v);)
+    } else if (vec && !g.out_f32 && g.act == MISSM_ACT_DQGELU) {        // backward through the activation
+      T* C = static_cast<T*>(g.C);
+      const T* U = static_cast<const T*>(g.aux_in);
+      MISSM_EPI_LOOP(const f32x4 u = load4(U + (size_t)row * g.ldaux + col);
+                     v[0] *= quick_gelu_grad(u[0]); v[1] *= quick_gelu_grad(u[1]); v[2] *= quick_gelu_grad(u[2]);
+                     v[3] *= quick_gelu_grad(u[3]); store4(C + off, v);)
+    } else if (vec && g.out_f32 && g.act == MISSM_ACT_NONE) {           // fp32 residual stream / fp32 outputs
+      float* C = static_cast<float*>(g.C);
+      const float* R = g.resid;
+      MISSM_EPI_LOOP(if (R) { const f32x4 q = load4(R + off); v += q; } store4(C + off, v);)
+    } else if (vec_atomic) {                                            // split-K partials of an NT product
+      float* C = static_cast<float*>(g.C);
+      MISSM_EPI_LOOP(atomicAdd(C + off, v[0]); atomicAdd(C + off + 1, v[1]); atomicAdd(C + off + 2, v[2]); atomicAdd(C + off + 3, v[3]);)
+    } else {                                                            // ragged edges, rare activations, accumulate
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = mw + i * 16 + lg * 4 + r;
+          if (row >= g.M) continue;
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (col + j < g.N)
+              epi_finish<T>(g, acc[i][j][r] * alpha + bias4[j], (size_t)row * g.ldc + col + j, (size_t)row * g.ldaux + col + j);
+        }
+    }
+#undef MISSM_EPI_LOOP
   }
 }
 
@@ -173,7 +215,7 @@ template <int RBK> __device__ __forceinline__ int kswz(int row, int chunk) {
   else return row * 64 + ((chunk ^ ((0x78 >> (((row >> 2) & 3) << 1)) & 3)) << 4);   // g = [0,2,3,1]: conflict-free b128 reads
 }
 
-template <typename T, bool TA, bool TB, int RBK>
+template <typename T, bool TA, bool TB, int RBK, int VAR = 0>
 __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(GemmArgs g) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
@@ -284,6 +326,25 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     if (kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);   // next tile lands in the other buffer under this tile's MFMAs
     const char* la = ldsA + buf * TILE_BYTES;
     const char* lb = ldsB + buf * TILE_BYTES;
+    if constexpr (VAR == 2 && !TA && !TB) {
+      // all fragments of the K tile are requested up front; MFMAs of step 0 start as soon as ITS fragments are back
+      Frag fa[KSTEPS][4], fb[KSTEPS][4];
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[ks][i] = lds_frag<T>(la, kswz<RBK>(wm * 64 + i * 16 + li, ks * 4 + lg));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) fb[ks][j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, ks * 4 + lg));
+      }
+      __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[ks][i], fb[ks][j], acc[i][j]);
+      __builtin_amdgcn_s_setprio(0);
+    } else {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       Frag fa[4], fb[4];
@@ -298,16 +359,19 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
         if constexpr (!TB) fb[j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, cchunk));
         else fb[j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
       }
+      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
+      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
       if constexpr (TA) {
         if (do_cs) {
 #pragma unroll
           for (int i = 0; i < 4; ++i) accb[i] = M_::step(fa[i], ones, accb[i]);
         }
       }
+    }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -735,6 +799,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate; g.colsum_a = colsum_a;
+  static const int variant = getenv("MISSM_GEMM_VARIANT") ? atoi(getenv("MISSM_GEMM_VARIANT")) : -1;   // scheduling experiments
   static const int force_kernel = getenv("MISSM_GEMM_KERNEL") ? atoi(getenv("MISSM_GEMM_KERNEL")) : 0;   // tuning knob: 1 / 3 / 4
   // 256x256 / 4-stage kernel: the grid must still cover the 256 CUs several times at one workgroup per CU
   const int t4 = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
@@ -826,9 +891,14 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // 32-deep K tiles / 4 workgroups per CU: +3..6 % on the video tower's K = 768 GEMMs (many tiles), -3..20 % on small grids
   const bool shortk = !trans_a && force_bk != 64 && (force_bk == 32 || (K <= 1024 && tiles >= 1024));
+  // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
+  // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
+  const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 1 : (K > 1024 ? 2 : 1));
 #define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
   do {                                                                                                     \
     if (shortk) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 64>), grid, block, 0, s, g);                     \
+    else if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 0, s, g);          \
+    else if (var == 2) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 2>), grid, block, 0, s, g);          \
     else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 0, s, g);                           \
   } while (0)
   if (dtype == kBF16) {
