@@ -890,13 +890,14 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   }
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // 32-deep K tiles / 4 workgroups per CU: +3..6 % on the video tower's K = 768 GEMMs (many tiles), -3..20 % on small grids
-  const bool shortk = !trans_a && force_bk != 64 && (force_bk == 32 || (K <= 1024 && tiles >= 1024));
+  // (re-measured after the epilogue was compacted: the 64-deep tile wins on every hot-path shape; knob kept)
+  const bool shortk = !trans_a && force_bk == 32;
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
   const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 1 : (K > 1024 ? 2 : 1));
 #define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
   do {                                                                                                     \
-    if (shortk) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 64>), grid, block, 0, s, g);                     \
+    if (shortk) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 64, 1>), grid, block, 0, s, g);                  \
     else if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 0, s, g);          \
     else if (var == 2) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 2>), grid, block, 0, s, g);          \
     else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 0, s, g);                           \
