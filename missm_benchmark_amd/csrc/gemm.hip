@@ -35,6 +35,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vec_ok;             // ldc/ldaux/pointers allow 16-byte (fp32) / 8-byte (bf16) vector epilogue accesses
   int splitk, k_per_split;  // splitk > 1: each K slice atomically adds its partial into the (zeroed) fp32 C
+  int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
 };
 
@@ -71,6 +72,19 @@ template <int COLS> struct KMajorFrag<float, COLS> {
     return v;
   }
 };
+
+// Grouped tile order: consecutive logical ids walk DOWN a group of `gm` tile rows before moving to the next tile column,
+// so the ~64 workgroups resident on one XCD cover a gm x (64/gm) patch of tiles and share gm A panels and 64/gm B panels
+// in that XCD's 4 MiB L2, instead of one A panel and every B panel (fc1's 4.7 MB weight does not fit next to A).
+__device__ __forceinline__ void tile_of(int logical, int tiles_m, int tiles_n, int gm, int& tm, int& tn) {
+  const int per_group = gm * tiles_n;
+  const int grp = logical / per_group;
+  const int first = grp * gm;
+  const int rows = min(gm, tiles_m - first);
+  const int in = logical - grp * per_group;
+  tm = first + in % rows;
+  tn = in / rows;
+}
 
 // Epilogue of one wave's 64x64 accumulator block whose top-left element is (mw, nw).
 // !TB: lane owns rows 4*lg + r of each 16-row tile i and the 4 CONSECUTIVE columns 4*li + j  (vector accesses)
@@ -240,7 +254,8 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   const int bid = blockIdx.x;
   const int split = bid / ntiles;
   const int logical = xcd_remap(bid - split * ntiles, ntiles);
-  const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
+  int tm, tn;
+  tile_of(logical, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -426,7 +441,8 @@ __global__ __launch_bounds__(G3_THREADS, 2) void gemm3_kernel(GemmArgs g) {
   const int bid = blockIdx.x;
   const int split = bid / ntiles;
   const int logical = xcd_remap(bid - split * ntiles, ntiles);
-  const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
+  int tm, tn;
+  tile_of(logical, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
   const int m0 = tm * G3_BM, n0 = tn * G3_BN;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -566,7 +582,8 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(GemmArgs g) {
   const int bid = blockIdx.x;
   const int split = bid / ntiles;
   const int logical = xcd_remap(bid - split * ntiles, ntiles);
-  const int tm = logical / g.tiles_n, tn = logical % g.tiles_n;
+  int tm, tn;
+  tile_of(logical, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
   const int m0 = tm * G4_BM, n0 = tn * G4_BN;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -799,6 +816,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate; g.colsum_a = colsum_a;
+  static const int group_m_env = getenv("MISSM_GEMM_GROUP_M") ? atoi(getenv("MISSM_GEMM_GROUP_M")) : 0;
+  g.group_m = 1;   // set once the tile grid is known
   static const int variant = getenv("MISSM_GEMM_VARIANT") ? atoi(getenv("MISSM_GEMM_VARIANT")) : -1;   // scheduling experiments
   static const int force_kernel = getenv("MISSM_GEMM_KERNEL") ? atoi(getenv("MISSM_GEMM_KERNEL")) : 0;   // tuning knob: 1 / 3 / 4
   // 256x256 / 4-stage kernel: the grid must still cover the 256 CUs several times at one workgroup per CU
@@ -818,6 +837,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + bn - 1) / bn;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
              ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
+  // measured on the video tower (GROUP_M 1 / 8 / 16): QKV 668 / 732 / 756, fc1 646 / 692 / 703, fc2 (6 tile columns) 795 / 772 / 729
+  g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 12 ? 16 : (g.tiles_n >= 8 ? 8 : 1));
   const int bk = dtype == kBF16 ? 64 : 32;
   const int tiles = g.tiles_m * g.tiles_n;
   static const int force_bk = getenv("MISSM_GEMM_BK") ? atoi(getenv("MISSM_GEMM_BK")) : 0;   // tuning knob (32 / 64)
