@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=8)
+    ap.add_argument("--gemm-table", action="store_true", help="print per-shape GEMM time/TFLOP/s of the roofline pass to stderr")
     ap.add_argument("--serial-streams", action="store_true", help="encode the modalities on one stream (per-kernel timings are then exclusive)")
     return ap.parse_args()
 
@@ -216,8 +217,14 @@ def main():
 
     roof = None
     if prof:
-        flops = sum(f for _, _, f in prof)
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in prof)
+        flops = sum(p[2] for p in prof)
+        ms = sum(p[0].elapsed_time(p[1]) for p in prof)
+        if args.gemm_table and rank == 0:
+            agg = {}
+            for e0, e1, f, shape in prof:
+                a = agg.setdefault(shape, [0, 0.0, 0.0]); a[0] += 1; a[1] += e0.elapsed_time(e1); a[2] += f
+            for shape, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
+                print(f"[gemm] M,N,K,tA,tB,act={shape}: {n:4d} launches {t:8.2f} ms  {f / t / 1e9:7.1f} TFLOP/s", file=sys.stderr)
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"kernel": "gemm_kernel<bf16,*> + gemm3_kernel<bf16,*> (MFMA GEMM family)" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",

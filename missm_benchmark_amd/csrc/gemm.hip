@@ -843,11 +843,13 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   const int tiles = g.tiles_m * g.tiles_n;
   static const int force_bk = getenv("MISSM_GEMM_BK") ? atoi(getenv("MISSM_GEMM_BK")) : 0;   // tuning knob (32 / 64)
   const int fill = (big || huge) ? 256 : 512;   // workgroups that fill the chip once (1 resp. 2 per CU)
-  if (splitk <= 0) {  // auto: only worth it when the tile grid cannot fill the 256 CUs
+  if (splitk <= 0) {  // auto: fill the chip exactly ONCE (2 workgroups x 256 CUs) - one resident wave of blocks, no tail.
+    // Measured (dW shapes, tiles x splits): 144x3 = 432 -> 427-596 TFLOP/s, 144x4 = 576 -> 280-420 (a second, nearly empty
+    // round), 36x12 -> 506 vs 36x8 -> 379; fewer splits also means fewer fp32 atomics (1.3 TB/s chip-wide).
     splitk = 1;
     if (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE && tiles < fill) {
-      splitk = (2 * fill) / tiles;
-      const int maxs = K / (8 * bk);
+      splitk = fill / tiles;
+      const int maxs = K / (4 * bk);
       if (splitk > maxs) splitk = maxs;
       if (splitk < 1) splitk = 1;
     }

@@ -81,7 +81,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
               int(accumulate), int(splitk), _p(colsum_a), dt(a), _s())
     if prof is not None:
         e1.record()
-        prof.append((e0, e1, 2.0 * M * N * K))
+        prof.append((e0, e1, 2.0 * M * N * K, (M, N, K, int(trans_a), int(trans_b), act)))
     return out
 
 
