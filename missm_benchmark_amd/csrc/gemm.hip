@@ -35,6 +35,7 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vec_ok;             // ldc/ldaux/pointers allow 16-byte (fp32) / 8-byte (bf16) vector epilogue accesses
   int splitk, k_per_split;  // splitk > 1: each K slice atomically adds its partial into the (zeroed) fp32 C
+  unsigned long long* dbg;  // diagnostic builds only: per-workgroup {start, loop start, loop end, end, hw id} stamps (100 MHz clock)
   int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
 };
@@ -114,8 +115,21 @@ __device__ __forceinline__ void epi_finish(const GemmArgs& g, float x, size_t of
   }
 }
 
+// bias of the 4 consecutive output columns a lane owns, fetched at kernel start so its latency hides under the main loop
+__device__ __forceinline__ f32x4 prefetch_bias(const GemmArgs& g, int nw, int split, int lane) {
+  f32x4 b = {0.f, 0.f, 0.f, 0.f};
+  const int col = nw + (lane & 15) * 4;
+  if (g.bias && split == 0 && col < g.N) {
+    if (col + 3 < g.N) b = load4(g.bias + col);
+    else
+      for (int j = 0; j < 4; ++j) if (col + j < g.N) b[j] = g.bias[col + j];
+  }
+  return b;
+}
+
 template <typename T, bool TB>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane) {
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane,
+                                              f32x4 bias4) {
   const int li = lane & 15, lg = lane >> 4;
   const bool first_split = split == 0;
   if constexpr (TB) {
@@ -159,12 +173,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
   } else {
     const int col = nw + li * 4;
     if (col >= g.N) return;
-    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (g.bias && first_split) {
-      if (col + 3 < g.N) bias4 = load4(g.bias + col);
-      else
-        for (int j = 0; j < 4; ++j) if (col + j < g.N) bias4[j] = g.bias[col + j];
-    }
     const float alpha = g.alpha;
     const bool vec = (col + 3 < g.N) && g.vec_ok && g.splitk == 1 && g.act != MISSM_ACT_RELU && g.act != MISSM_ACT_GELU &&
                      g.act != MISSM_ACT_DGELU && !g.accumulate;
@@ -332,9 +340,13 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk <= 0) return;
+  unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;
+  if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
+  const f32x4 bias4 = prefetch_bias(g, n0 + wn * 64, split, lane);
   stage(0, kbeg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (g.dbg) t_loop = __builtin_amdgcn_s_memrealtime();
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
@@ -403,7 +415,16 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     }
   }
 
-  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
+  if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
+  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane, bias4);
+  if (g.dbg && tid == 0) {
+    const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.dbg[(size_t)blockIdx.x * 8 + 5] = t_issued;
+    unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
+    unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = __builtin_amdgcn_s_memrealtime(); d[4] = hw;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -548,7 +569,7 @@ __global__ __launch_bounds__(G3_THREADS, 2) void gemm3_kernel(GemmArgs g) {
     }
     st = st + 1 >= G3_STAGES ? 0 : st + 1;
   }
-  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane);
+  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane, prefetch_bias(g, n0 + wn * 64, split, lane));
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -680,8 +701,9 @@ __global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(GemmArgs g) {
       for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = M_::step(fa[i], fb[j], acc[i >> 2][i & 3][j]);
     st = (st + 1) & 3;
   }
-  gemm_epilogue<T, TB>(g, acc[0], m0 + wm * 128, n0 + wn * 64, split, lane);
-  gemm_epilogue<T, TB>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, split, lane);
+  const f32x4 b4 = prefetch_bias(g, n0 + wn * 64, split, lane);
+  gemm_epilogue<T, TB>(g, acc[0], m0 + wm * 128, n0 + wn * 64, split, lane, b4);
+  gemm_epilogue<T, TB>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, split, lane, b4);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -798,6 +820,9 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
 
 using namespace missm;
 
+static unsigned long long* missm_gemm_debug_buffer = nullptr;
+extern "C" void missm_gemm_set_debug_buffer(void* p) { missm_gemm_debug_buffer = static_cast<unsigned long long*>(p); }
+
 extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                           int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
                           int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream) {
@@ -818,6 +843,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.out_f32 = out_f32; g.accumulate = accumulate; g.colsum_a = colsum_a;
   static const int group_m_env = getenv("MISSM_GEMM_GROUP_M") ? atoi(getenv("MISSM_GEMM_GROUP_M")) : 0;
   g.group_m = 1;   // set once the tile grid is known
+  g.dbg = missm_gemm_debug_buffer;
   static const int variant = getenv("MISSM_GEMM_VARIANT") ? atoi(getenv("MISSM_GEMM_VARIANT")) : -1;   // scheduling experiments
   static const int force_kernel = getenv("MISSM_GEMM_KERNEL") ? atoi(getenv("MISSM_GEMM_KERNEL")) : 0;   // tuning knob: 1 / 3 / 4
   // 256x256 / 4-stage kernel: the grid must still cover the 256 CUs several times at one workgroup per CU
