@@ -226,7 +226,7 @@ def main():
             for shape, (n, t, f) in sorted(agg.items(), key=lambda kv: -kv[1][1]):
                 print(f"[gemm] M,N,K,tA,tB,act={shape}: {n:4d} launches {t:8.2f} ms  {f / t / 1e9:7.1f} TFLOP/s", file=sys.stderr)
         ach = flops / (ms * 1e-3) / 1e12
-        roof = {"kernel": "gemm_kernel<bf16,*> + gemm3_kernel<bf16,*> (MFMA GEMM family)" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
+        roof = {"kernel": "gemm_kernel<bf16,TA,TB,128,VAR> (the MFMA GEMM behind every linear, dX and dW)" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                 "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
                 "launches": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),

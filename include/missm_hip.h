@@ -64,6 +64,10 @@ int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int l
                float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act,
                int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream);
 
+/* Diagnostic only: when set (device pointer to 8 x uint64 per workgroup), the next GEMM launches record per-workgroup
+ * {start, first tile landed, main loop end, end, HW_ID, stores issued} stamps of the 100 MHz clock; NULL switches it off. */
+void missm_gemm_set_debug_buffer(void* stamps);
+
 /* out[C, ldo] = in[R, C]^T zero-padded to ldo columns; optional colsum[C] += column sums (bias gradient). */
 int missm_transpose_pad(const void* in, void* out, int R, int C, int ld, int ldo, float* colsum, int dtype, void* stream);
 /* out[(row / div) % mod][c] += in[row][c]  (position / temporal embedding and bias gradients). */

@@ -427,284 +427,18 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   }
 }
 
-// ---------------------------------------------------------------------------------------------------
-// 256x128 tile, 8 waves (4 x 2, 64x64 each), 3-stage LDS ring filled by global_load_lds with TWO K tiles in flight:
-//   loop:  s_waitcnt vmcnt(6)   -> this wave's 6 pieces of tile kt have landed (tile kt+1 stays in flight)
-//          s_barrier            -> everybody's pieces landed; everybody is done reading the stage tile kt+2 will overwrite
-//          issue tile kt+2      -> 6 x global_load_lds_dwordx4 per wave
-//          32 MFMA + 16 LDS fragment reads on tile kt
-// One barrier per K tile, never a vmcnt(0) inside the loop, all LDS in one (dynamic) array.  144 KiB of LDS -> one
-// 512-thread workgroup per CU (2 waves per SIMD); 0.75x the L2->LDS bytes per FLOP of the 128x128 kernel.
-// (A persistent variant that keeps the ring running across output tiles was measured SLOWER - 845 -> 665 TFLOP/s at
-//  4096^3 - because the counted vmcnt then also waits for the previous tile's epilogue stores.)
-// ---------------------------------------------------------------------------------------------------
-constexpr int G3_BM = 256, G3_BN = 128, G3_THREADS = 512, G3_STAGES = 3;
-constexpr int G3_STAGE_BYTES = (G3_BM + G3_BN) * RB;   // 48 KiB
-constexpr int G3_LDS_BYTES = G3_STAGES * G3_STAGE_BYTES;
-
-template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(G3_THREADS, 2) void gemm3_kernel(GemmArgs g) {
-  using M_ = Mma<T>;
-  using Frag = typename M_::Frag;
-  constexpr int EPC = 16 / sizeof(T);
-  constexpr int BK = RB / sizeof(T);
-  constexpr int KSTEPS = BK / M_::KS;
-  constexpr int RBTA = KMajorFrag<T, G3_BM>::RBT, NCTA = RBTA / 16;   // k-major A tile rows: 256 elements
-  constexpr int RBTB = KMajorFrag<T, G3_BN>::RBT, NCTB = RBTB / 16;   // k-major B tile rows: 128 elements
-  constexpr int A_BYTES = G3_BM * RB;                                 // 32 KiB either layout
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
-
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int bid = blockIdx.x;
-  const int split = bid / ntiles;
-  const int logical = xcd_remap(bid - split * ntiles, ntiles);
-  int tm, tn;
-  tile_of(logical, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-  const int m0 = tm * G3_BM, n0 = tn * G3_BN;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-
-  const T* __restrict__ A = static_cast<const T*>(g.A);
-  const T* __restrict__ B = static_cast<const T*>(g.B);
-
-  // staging: A tile = 32 pieces of 1 KiB (4 per wave), B tile = 16 pieces (2 per wave)
-  const T* a_src[4];
-  const T* b_src[2];
-  bool a_ok[4], b_ok[2];
-  int a_kofs[4], b_kofs[2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int pi = wave * 4 + i;
-    if constexpr (!TA) {
-      const int row = 8 * pi + (lane >> 3), c = (lane & 7) ^ (row & 7);
-      int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-      a_src[i] = A + (size_t)gr * g.lda + c * EPC;
-      a_ok[i] = true; a_kofs[i] = c * EPC;
-    } else {
-      constexpr int RPP = 1024 / RBTA;     // 2 (bf16) or 1 (f32) k rows per piece
-      const int row = RPP * pi + lane / NCTA, c = (lane % NCTA) ^ (tkey(row) << 1);
-      a_src[i] = A + (size_t)row * g.lda + m0 + c * EPC;
-      a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = row;
-    }
-  }
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pi = wave * 2 + i;
-    if constexpr (!TB) {
-      const int lr = 8 * pi + (lane >> 3), c = (lane & 7) ^ (lr & 7);
-      const int r = (lr & 64) + ((lr & 15) << 2) + ((lr >> 4) & 3);
-      int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
-      b_src[i] = B + (size_t)gn * g.ldb + c * EPC;
-      b_ok[i] = true; b_kofs[i] = c * EPC;
-    } else {
-      constexpr int RPP = 1024 / RBTB;
-      const int row = RPP * pi + lane / NCTB, c = (lane % NCTB) ^ (tkey(row) << 1);
-      b_src[i] = B + (size_t)row * g.ldb + n0 + c * EPC;
-      b_ok[i] = (n0 + c * EPC) < g.N; b_kofs[i] = row;
-    }
-  }
-  using gptr = const __attribute__((address_space(1))) void*;
-  using lptr = __attribute__((address_space(3))) void*;
-  auto stage = [&](int st, int k0) {
-    char* la = lds + st * G3_STAGE_BYTES + wave * 4096;
-    char* lb = lds + st * G3_STAGE_BYTES + A_BYTES + wave * 2048;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const T* pa = (a_ok[i] && (k0 + a_kofs[i]) < kend) ? (TA ? a_src[i] + (size_t)k0 * g.lda : a_src[i] + k0)
-                                                          : reinterpret_cast<const T*>(g_zero16);
-      __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(la + i * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const T* pb = (b_ok[i] && (k0 + b_kofs[i]) < kend) ? (TB ? b_src[i] + (size_t)k0 * g.ldb : b_src[i] + k0)
-                                                          : reinterpret_cast<const T*>(g_zero16);
-      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(lb + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk <= 0) return;
-  stage(0, kbeg);
-  if (nk > 1) stage(1, kbeg + BK);
-
-  int st = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 2 < nk) {
-      int st2 = st + 2; st2 = st2 >= G3_STAGES ? st2 - G3_STAGES : st2;
-      stage(st2, kbeg + (kt + 2) * BK);
-    }
-    const char* la = lds + st * G3_STAGE_BYTES;
-    const char* lb = la + A_BYTES;
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-      Frag fa[4], fb[4];
-      const int cbyte = (ks * 4 + lg) * 16;
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        if constexpr (!TA) fa[i] = lds_frag<T>(la, swz<RB>(wm * 64 + i * 16 + li, cbyte));
-        else fa[i] = KMajorFrag<T, G3_BM>::load(la, ks, wm * 64 + i * 16, lane);
-      }
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if constexpr (!TB) fb[j] = lds_frag<T>(lb, swz<RB>(wn * 64 + j * 16 + li, cbyte));
-        else fb[j] = KMajorFrag<T, G3_BN>::load(lb, ks, wn * 64 + j * 16, lane);
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
-    }
-    st = st + 1 >= G3_STAGES ? 0 : st + 1;
-  }
-  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane, prefetch_bias(g, n0 + wn * 64, split, lane));
-}
-
-// ---------------------------------------------------------------------------------------------------
-// 256x256 tile, 8 waves (2 x 4, 128x64 per wave = 8x4 MFMA tiles), K tile 32 (64-byte LDS rows), 4-stage ring with THREE
-// K tiles in flight:  s_waitcnt vmcnt(8) -> s_barrier -> issue tile kt+3 (4 x global_load_lds per wave) -> 32 MFMA on
-// tile kt fed by 12 ds_read_b128.  Half the L2->LDS bytes and 3/4 of the LDS reads per FLOP of the 128x128 kernel (the
-// per-CU vector-memory path, 64 B/clk, is what the smaller tiles run into).  128 KiB LDS, one workgroup per CU, so it is
-// only dispatched when the tile grid still covers the chip several times (the video tower: 50 432 rows).
-// ---------------------------------------------------------------------------------------------------
-constexpr int G4_BM = 256, G4_BN = 256, G4_THREADS = 512, G4_STAGES = 4, G4_RB = 64;
-constexpr int G4_A_BYTES = G4_BM * G4_RB;                       // 16 KiB
-constexpr int G4_STAGE_BYTES = (G4_BM + G4_BN) * G4_RB;         // 32 KiB
-constexpr int G4_LDS_BYTES = G4_STAGES * G4_STAGE_BYTES;        // 128 KiB
-
-template <typename T, bool TA, bool TB>
-__global__ __launch_bounds__(G4_THREADS, 2) void gemm4_kernel(GemmArgs g) {
-  using M_ = Mma<T>;
-  using Frag = typename M_::Frag;
-  constexpr int EPC = 16 / sizeof(T);
-  constexpr int BK = G4_RB / sizeof(T);                 // 32 bf16 / 16 f32 = exactly one MFMA step
-  static_assert(BK == M_::KS, "one MFMA step per K tile");
-  constexpr int RBTA = KMajorFrag<T, G4_BM>::RBT, NCTA = RBTA / 16;
-  constexpr int RBTB = KMajorFrag<T, G4_BN>::RBT, NCTB = RBTB / 16;
-  extern __shared__ __attribute__((aligned(16))) char lds[];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int li = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 2, wn = wave & 3;              // 2 x 4 waves
-
-  const int ntiles = g.tiles_m * g.tiles_n;
-  const int bid = blockIdx.x;
-  const int split = bid / ntiles;
-  const int logical = xcd_remap(bid - split * ntiles, ntiles);
-  int tm, tn;
-  tile_of(logical, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-  const int m0 = tm * G4_BM, n0 = tn * G4_BN;
-  const int kbeg = split * g.k_per_split;
-  const int kend = min(g.K, kbeg + g.k_per_split);
-
-  const T* __restrict__ A = static_cast<const T*>(g.A);
-  const T* __restrict__ B = static_cast<const T*>(g.B);
-
-  // staging: A and B tiles are 16 pieces of 1 KiB each -> 2 + 2 pieces per wave
-  const T* a_src[2];
-  const T* b_src[2];
-  bool a_ok[2], b_ok[2];
-  int a_kofs[2], b_kofs[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int pi = wave * 2 + i;
-    if constexpr (!TA) {
-      const int row = 16 * pi + (lane >> 2), c = (kswz<64>(row, lane & 3) - row * 64) >> 4;
-      int gr = m0 + row; gr = gr < g.M ? gr : g.M - 1;
-      a_src[i] = A + (size_t)gr * g.lda + c * EPC;
-      a_ok[i] = true; a_kofs[i] = c * EPC;
-    } else {
-      constexpr int RPP = 1024 / RBTA;     // 2 (bf16) or 1 (f32) k rows per piece
-      const int row = RPP * pi + lane / NCTA, c = (lane % NCTA) ^ (tkey(row) << 1);
-      a_src[i] = A + (size_t)row * g.lda + m0 + c * EPC;
-      a_ok[i] = (m0 + c * EPC) < g.M; a_kofs[i] = row;
-    }
-    if constexpr (!TB) {
-      const int lr = 16 * pi + (lane >> 2), c = (kswz<64>(lr, lane & 3) - lr * 64) >> 4;
-      const int r = (lr & ~63) + ((lr & 15) << 2) + ((lr >> 4) & 3);   // LDS row lr <- tile row r (lane owns 4 consecutive columns)
-      int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
-      b_src[i] = B + (size_t)gn * g.ldb + c * EPC;
-      b_ok[i] = true; b_kofs[i] = c * EPC;
-    } else {
-      constexpr int RPP = 1024 / RBTB;
-      const int row = RPP * pi + lane / NCTB, c = (lane % NCTB) ^ (tkey(row) << 1);
-      b_src[i] = B + (size_t)row * g.ldb + n0 + c * EPC;
-      b_ok[i] = (n0 + c * EPC) < g.N; b_kofs[i] = row;
-    }
-  }
-  using gptr = const __attribute__((address_space(1))) void*;
-  using lptr = __attribute__((address_space(3))) void*;
-  auto stage = [&](int st, int k0) {
-    char* la = lds + st * G4_STAGE_BYTES + wave * 2048;
-    char* lb = la + G4_A_BYTES;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const T* pa = (a_ok[i] && (k0 + a_kofs[i]) < kend) ? (TA ? a_src[i] + (size_t)k0 * g.lda : a_src[i] + k0)
-                                                          : reinterpret_cast<const T*>(g_zero16);
-      const T* pb = (b_ok[i] && (k0 + b_kofs[i]) < kend) ? (TB ? b_src[i] + (size_t)k0 * g.ldb : b_src[i] + k0)
-                                                          : reinterpret_cast<const T*>(g_zero16);
-      __builtin_amdgcn_global_load_lds((gptr)pa, (lptr)(la + i * 1024), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((gptr)pb, (lptr)(lb + i * 1024), 16, 0, 0);
-    }
-  };
-
-  f32x4 acc[2][4][4];
-#pragma unroll
-  for (int h = 0; h < 2; ++h)
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[h][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const int nk = (kend - kbeg + BK - 1) / BK;
-  if (nk <= 0) return;
-  stage(0, kbeg);
-  if (nk > 1) stage(1, kbeg + BK);
-  if (nk > 2) stage(2, kbeg + 2 * BK);
-
-  int st = 0;
-  for (int kt = 0; kt < nk; ++kt) {
-    // tiles kt+1 and kt+2 (4 loads each) may stay in flight; only tile kt has to have landed
-    if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if (kt + 1 < nk) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    if (kt + 3 < nk) stage((st + 3) & 3, kbeg + (kt + 3) * BK);
-    const char* la = lds + st * G4_STAGE_BYTES;
-    const char* lb = la + G4_A_BYTES;
-    Frag fa[8], fb[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      if constexpr (!TB) fb[j] = lds_frag<T>(lb, kswz<64>(wn * 64 + j * 16 + li, lg));
-      else fb[j] = KMajorFrag<T, G4_BN>::load(lb, 0, wn * 64 + j * 16, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      if constexpr (!TA) fa[i] = lds_frag<T>(la, kswz<64>(wm * 128 + i * 16 + li, lg));
-      else fa[i] = KMajorFrag<T, G4_BM>::load(la, 0, wm * 128 + i * 16, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i)
-#pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i >> 2][i & 3][j] = M_::step(fa[i], fb[j], acc[i >> 2][i & 3][j]);
-    st = (st + 1) & 3;
-  }
-  const f32x4 b4 = prefetch_bias(g, n0 + wn * 64, split, lane);
-  gemm_epilogue<T, TB>(g, acc[0], m0 + wm * 128, n0 + wn * 64, split, lane, b4);
-  gemm_epilogue<T, TB>(g, acc[1], m0 + wm * 128 + 64, n0 + wn * 64, split, lane, b4);
-}
+// Measured and removed again (git history has them; all correct, none faster on the hot-path shapes):
+//   * 256x128 / 8 waves / 3-stage ring with counted vmcnt, one workgroup per CU : 845 TFLOP/s at 4096^3, 570-750 on the
+//     K = 768 video shapes (every tile's fill/drain is exposed with a single resident workgroup);
+//   * 256x256 / 8 waves / K tile 32 / 4-stage ring                              : 862 at 4096^3, 400-670 on the video shapes;
+//   * 128x128 / K tile 32 / 4-stage ring, two workgroups per CU                 : 768 at 4096^3, 615-650 on the video shapes;
+//   * the same ring kept running across output tiles (persistent workgroups)    : 665 at 4096^3 (the counted vmcnt then also
+//     waits for the previous tile's epilogue stores);
+//   * staggering co-resident workgroups by 6-25 us                               : -2..-5 %.
+// What did pay: global_load_lds staging, s_setprio around the MFMA cluster (+4-10 % at K = 768), requesting all fragments
+// of a K tile up front (+10 % at long K), a compact epilogue (instruction cache; +16 % at K = 768), bias prefetch, split-K
+// sized to ONE resident wave of workgroups, grouped tile order.  This kernel: 1088 TFLOP/s at 4096^3, 740-830 on the video
+// tower's K = 768 shapes (random data, one MI355X).
 
 // ---------------------------------------------------------------------------------------------------
 // 64x64 tiled transpose with zero padding of the new inner dimension and an optional fused column sum
@@ -845,22 +579,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.group_m = 1;   // set once the tile grid is known
   g.dbg = missm_gemm_debug_buffer;
   static const int variant = getenv("MISSM_GEMM_VARIANT") ? atoi(getenv("MISSM_GEMM_VARIANT")) : -1;   // scheduling experiments
-  static const int force_kernel = getenv("MISSM_GEMM_KERNEL") ? atoi(getenv("MISSM_GEMM_KERNEL")) : 0;   // tuning knob: 1 / 3 / 4
-  // 256x256 / 4-stage kernel: the grid must still cover the 256 CUs several times at one workgroup per CU
-  const int t4 = ((M + G4_BM - 1) / G4_BM) * ((N + G4_BN - 1) / G4_BN);
-  bool huge = false;   // measured: 862 TFLOP/s at 4096^3 (= the 128x128 kernel) but 400-670 on the K = 768 video shapes
-                       // (one workgroup per CU exposes every tile's fill/drain); kept behind MISSM_GEMM_KERNEL=4
-  (void)t4;
-  // 256x128 / 3-stage kernel: wins for long reductions on a full chip (845 vs ~750 TFLOP/s at 4096^3); at K = 768 its
-  // one-workgroup-per-CU fill/drain costs what the deeper pipeline gains, and split-K slices prefer 2 workgroups per CU.
-  bool big = !huge && !trans_a && M >= 1024 && K >= 2048 && ((M + G3_BM - 1) / G3_BM) * ((N + BN - 1) / BN) >= 192;
-  if (force_kernel == 1) { huge = false; big = false; }
-  if (force_kernel == 3) { huge = false; big = M >= 256; }
-  if (force_kernel == 4) { huge = M >= 256 && N >= 256; big = false; }
-  if (colsum_a) { huge = false; big = false; }   // the ones-column lives in the 128x128 kernel only
-  const int bm = huge ? G4_BM : (big ? G3_BM : BM);
-  const int bn = huge ? G4_BN : BN;
-  g.tiles_m = (M + bm - 1) / bm; g.tiles_n = (N + bn - 1) / bn;
+  g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
              ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
   // measured on the video tower (GROUP_M 1 / 8 / 16): QKV 668 / 732 / 756, fc1 646 / 692 / 703, fc2 (6 tile columns) 795 / 772 / 729
@@ -868,7 +587,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   const int bk = dtype == kBF16 ? 64 : 32;
   const int tiles = g.tiles_m * g.tiles_n;
   static const int force_bk = getenv("MISSM_GEMM_BK") ? atoi(getenv("MISSM_GEMM_BK")) : 0;   // tuning knob (32 / 64)
-  const int fill = (big || huge) ? 256 : 512;   // workgroups that fill the chip once (1 resp. 2 per CU)
+  const int fill = 512;   // workgroups that fill the chip once (2 per CU)
   if (splitk <= 0) {  // auto: fill the chip exactly ONCE (2 workgroups x 256 CUs) - one resident wave of blocks, no tail.
     // Measured (dW shapes, tiles x splits): 144x3 = 432 -> 427-596 TFLOP/s, 144x4 = 576 -> 280-420 (a second, nearly empty
     // round), 36x12 -> 506 vs 36x8 -> 379; fewer splits also means fewer fp32 atomics (1.3 TB/s chip-wide).
@@ -887,56 +606,6 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   splitk = (K + kps - 1) / kps;
   g.splitk = splitk; g.k_per_split = kps;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (huge) {
-    dim3 grid(tiles * splitk), block(G4_THREADS);
-#define MISSM_GEMM4_LAUNCH(T, TA, TB)                                                                                   \
-    do {                                                                                                                \
-      static bool attr_done = false;                                                                                    \
-      if (!attr_done) {                                                                                                 \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4_kernel<T, TA, TB>),                       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G4_LDS_BYTES);                   \
-        if (e != hipSuccess) { missm_set_error("gemm: cannot reserve %d bytes of LDS: %s", G4_LDS_BYTES, hipGetErrorString(e)); return MISSM_ERR_LAUNCH; } \
-        attr_done = true;                                                                                               \
-      }                                                                                                                 \
-      hipLaunchKernelGGL((gemm4_kernel<T, TA, TB>), grid, block, G4_LDS_BYTES, s, g);                                    \
-    } while (0)
-    if (dtype == kBF16) {
-      if (!trans_a && !trans_b) MISSM_GEMM4_LAUNCH(bf16, false, false);
-      else if (!trans_a && trans_b) MISSM_GEMM4_LAUNCH(bf16, false, true);
-      else MISSM_GEMM4_LAUNCH(bf16, true, true);
-    } else {
-      if (!trans_a && !trans_b) MISSM_GEMM4_LAUNCH(float, false, false);
-      else if (!trans_a && trans_b) MISSM_GEMM4_LAUNCH(float, false, true);
-      else MISSM_GEMM4_LAUNCH(float, true, true);
-    }
-#undef MISSM_GEMM4_LAUNCH
-    return missm_check_launch("gemm4");
-  }
-  if (big) {
-    dim3 grid(tiles * splitk), block(G3_THREADS);
-#define MISSM_GEMM3_LAUNCH(T, TA, TB)                                                                                   \
-    do {                                                                                                                \
-      static bool attr_done = false;                                                                                    \
-      if (!attr_done) {                                                                                                 \
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm3_kernel<T, TA, TB>),                       \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, G3_LDS_BYTES);                   \
-        if (e != hipSuccess) { missm_set_error("gemm: cannot reserve %d bytes of LDS: %s", G3_LDS_BYTES, hipGetErrorString(e)); return MISSM_ERR_LAUNCH; } \
-        attr_done = true;                                                                                               \
-      }                                                                                                                 \
-      hipLaunchKernelGGL((gemm3_kernel<T, TA, TB>), grid, block, G3_LDS_BYTES, s, g);                                    \
-    } while (0)
-    if (dtype == kBF16) {
-      if (!trans_a && !trans_b) MISSM_GEMM3_LAUNCH(bf16, false, false);
-      else if (!trans_a && trans_b) MISSM_GEMM3_LAUNCH(bf16, false, true);
-      else MISSM_GEMM3_LAUNCH(bf16, true, true);
-    } else {
-      if (!trans_a && !trans_b) MISSM_GEMM3_LAUNCH(float, false, false);
-      else if (!trans_a && trans_b) MISSM_GEMM3_LAUNCH(float, false, true);
-      else MISSM_GEMM3_LAUNCH(float, true, true);
-    }
-#undef MISSM_GEMM3_LAUNCH
-    return missm_check_launch("gemm3");
-  }
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // 32-deep K tiles / 4 workgroups per CU: +3..6 % on the video tower's K = 768 GEMMs (many tiles), -3..20 % on small grids
   // (re-measured after the epilogue was compacted: the 64-deep tile wins on every hot-path shape; knob kept)

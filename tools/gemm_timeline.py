@@ -4,7 +4,6 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, numpy as np
 from missm_benchmark_amd import ops, _lib
 lib = _lib.load()
-lib.missm_gemm_set_debug_buffer.argtypes = [ctypes.c_void_p]
 M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (50432, 3072, 768)
 dt = torch.bfloat16
 x = torch.randn(M, K, device="cuda").to(dt); w = torch.randn(N, K, device="cuda").to(dt)
