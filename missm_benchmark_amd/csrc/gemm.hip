@@ -127,15 +127,45 @@ __device__ __forceinline__ f32x4 prefetch_bias(const GemmArgs& g, int nw, int sp
   return b;
 }
 
+// Rare epilogue cases (ragged edges, relu / erf-gelu, accumulate, NN with an activation): the wave parks its 64x64 fp32
+// block in its own 16 KiB slice of the (now idle) LDS tile buffers and walks it with ONE rolled loop, so the general
+// code exists once per kernel instead of 64 times.  element (row, col) of the block lives at wave_lds[row * 64 + col].
+template <typename T, bool TB>
+__device__ __forceinline__ void epilogue_generic(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane,
+                                                 float* wave_lds) {
+  const int li = lane & 15, lg = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = i * 16 + lg * 4 + r;
+        const int col = TB ? j * 16 + li : li * 4 + j;
+        wave_lds[row * 64 + col] = acc[i][j][r];
+      }
+  // same-wave LDS traffic is ordered; no barrier needed (each wave reads back only its own slice)
+#pragma unroll 1
+  for (int e = lane; e < 64 * 64; e += 64) {
+    const int row = e >> 6, col = e & 63;
+    const int grow = mw + row, gcol = nw + col;
+    if (grow < g.M && gcol < g.N) {
+      const float bv = (g.bias && split == 0) ? g.bias[gcol] : 0.f;
+      epi_finish<T>(g, wave_lds[e] * g.alpha + bv, (size_t)grow * g.ldc + gcol, (size_t)grow * g.ldaux + gcol);
+    }
+  }
+}
+
 template <typename T, bool TB>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane,
-                                              f32x4 bias4) {
+                                              f32x4 bias4, float* wave_lds) {
   const int li = lane & 15, lg = lane >> 4;
   const bool first_split = split == 0;
   if constexpr (TB) {
     // (register arrays must only ever be indexed with compile-time constants: a rolled loop here sends `acc` to scratch)
     const bool atomic = g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
     const bool plain_t = !g.out_f32 && g.act == MISSM_ACT_NONE;
+    if (!atomic && !plain_t) { epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds); return; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = nw + j * 16 + li;
@@ -159,24 +189,17 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
             const int row = mw + i * 16 + lg * 4 + r;
             if (row < g.M) C[(size_t)row * g.ldc + col] = from_f32<T>(acc[i][j][r] * g.alpha + bv);
           }
-      } else {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = mw + i * 16 + lg * 4 + r;
-            if (row < g.M) epi_finish<T>(g, acc[i][j][r] * g.alpha + bv, (size_t)row * g.ldc + col, (size_t)row * g.ldaux + col);
-          }
       }
     }
     return;
   } else {
     const int col = nw + li * 4;
-    if (col >= g.N) return;
+    if (nw >= g.N) return;
     const float alpha = g.alpha;
-    const bool vec = (col + 3 < g.N) && g.vec_ok && g.splitk == 1 && g.act != MISSM_ACT_RELU && g.act != MISSM_ACT_GELU &&
+    // wave-uniform decisions only: the generic path exchanges data between the lanes of the wave through LDS
+    const bool vec = (nw + 64 <= g.N) && g.vec_ok && g.splitk == 1 && g.act != MISSM_ACT_RELU && g.act != MISSM_ACT_GELU &&
                      g.act != MISSM_ACT_DGELU && !g.accumulate;
-    const bool vec_atomic = (col + 3 < g.N) && g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
+    const bool vec_atomic = (nw + 64 <= g.N) && g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
     // value of (tile i, register r): 4 consecutive columns
 #define MISSM_EPI_LOOP(BODY)                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
@@ -213,17 +236,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
       float* C = static_cast<float*>(g.C);
       MISSM_EPI_LOOP(atomicAdd(C + off, v[0]); atomicAdd(C + off + 1, v[1]); atomicAdd(C + off + 2, v[2]); atomicAdd(C + off + 3, v[3]);)
     } else {                                                            // ragged edges, rare activations, accumulate
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = mw + i * 16 + lg * 4 + r;
-          if (row >= g.M) continue;
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (col + j < g.N)
-              epi_finish<T>(g, acc[i][j][r] * alpha + bias4[j], (size_t)row * g.ldc + col + j, (size_t)row * g.ldaux + col + j);
-        }
+      epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds);
     }
 #undef MISSM_EPI_LOOP
   }
@@ -416,7 +429,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   }
 
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
-  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane, bias4);
+  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384));
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -586,7 +599,6 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 12 ? 16 : (g.tiles_n >= 8 ? 8 : 1));
   const int bk = dtype == kBF16 ? 64 : 32;
   const int tiles = g.tiles_m * g.tiles_n;
-  static const int force_bk = getenv("MISSM_GEMM_BK") ? atoi(getenv("MISSM_GEMM_BK")) : 0;   // tuning knob (32 / 64)
   const int fill = 512;   // workgroups that fill the chip once (2 per CU)
   if (splitk <= 0) {  // auto: fill the chip exactly ONCE (2 workgroups x 256 CUs) - one resident wave of blocks, no tail.
     // Measured (dW shapes, tiles x splits): 144x3 = 432 -> 427-596 TFLOP/s, 144x4 = 576 -> 280-420 (a second, nearly empty
@@ -607,16 +619,13 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.splitk = splitk; g.k_per_split = kps;
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
-  // 32-deep K tiles / 4 workgroups per CU: +3..6 % on the video tower's K = 768 GEMMs (many tiles), -3..20 % on small grids
-  // (re-measured after the epilogue was compacted: the 64-deep tile wins on every hot-path shape; knob kept)
-  const bool shortk = !trans_a && force_bk == 32;
+  // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
   const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 1 : (K > 1024 ? 2 : 1));
 #define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
   do {                                                                                                     \
-    if (shortk) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 64, 1>), grid, block, 0, s, g);                  \
-    else if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 0, s, g);          \
+    if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 0, s, g);          \
     else if (var == 2) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 2>), grid, block, 0, s, g);          \
     else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 0, s, g);                           \
   } while (0)
