@@ -75,6 +75,10 @@ int missm_colsum(const void* in, float* out, int R, int C, int ld, int div, int 
 /* fp32 master weight [R,C] -> `dtype` shadow dst[R,C] and/or transposed shadow dst_t[C,R] (either may be NULL). */
 int missm_cast_weight(const float* src, void* dst, void* dst_t, int R, int C, int dtype, void* stream);
 
+/* The same for every weight block of a tower in one launch: `tiles` is a device array of ntiles records
+ * { const float* src; void* dst; void* dst_t; int R, C, r0, c0; } (40 bytes, one 64x64 tile each). */
+int missm_cast_weights_batched(const void* tiles, int ntiles, int dtype, void* stream);
+
 /* LayerNorm over fp32 rows.  Input row = x[row * in_mul + in_off[row]] (row gather for CLS / EOT pooling);
  * if `add` is given, add[(row / add_div) % add_mod] is added first and the sum written back to x_wb
  * (temporal_embedding).  Saves mean / rstd.  Replaces nn.LayerNorm at image/modeling_image.py:70,72,82,465,604,606,

@@ -19,6 +19,7 @@ SIGNATURES = {
     "missm_transpose_pad": [P, P, I, I, I, I, P, I, P],
     "missm_colsum": [P, P, I, I, I, I, I, I, P],
     "missm_cast_weight": [P, P, P, I, I, I, P],
+    "missm_cast_weights_batched": [P, I, I, P],
     "missm_layernorm_fwd": [P, P, P, I, I, I, P, P, P, P, P, P, I, I, F, I, P],
     "missm_layernorm_bwd": [P, I, F, P, I, P, P, P, P, P, I, P, P, P, I, I, I, P],
     "missm_cast_rows": [P, P, L, I, I, I, I, P],

@@ -563,6 +563,31 @@ __global__ __launch_bounds__(256) void cast_weight_kernel(const float* __restric
   }
 }
 
+// all weight blocks of a tower in ONE launch: one 64x64 tile per workgroup, described by a table built once on the host
+struct CastTile { const float* src; void* dst; void* dst_t; int R, C, r0, c0; };
+template <typename T>
+__global__ __launch_bounds__(256) void cast_weights_batched_kernel(const CastTile* __restrict__ tiles) {
+  __shared__ float tile[64][65];
+  const CastTile t = tiles[blockIdx.x];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  T* dst = static_cast<T*>(t.dst);
+  T* dst_t = static_cast<T*>(t.dst_t);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = t.r0 + ty + 4 * i, c = t.c0 + tx;
+    const float v = (r < t.R && c < t.C) ? t.src[(size_t)r * t.C + c] : 0.f;
+    tile[ty + 4 * i][tx] = v;
+    if (dst && r < t.R && c < t.C) dst[(size_t)r * t.C + c] = from_f32<T>(v);
+  }
+  if (!dst_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = t.c0 + ty + 4 * i, r = t.r0 + tx;
+    if (c < t.C && r < t.R) dst_t[(size_t)c * t.R + r] = from_f32<T>(tile[tx][ty + 4 * i]);
+  }
+}
+
 }  // namespace missm
 
 using namespace missm;
@@ -678,6 +703,14 @@ extern "C" int missm_colsum(const void* in, float* out, int R, int C, int ld, in
   if (dtype == kBF16) hipLaunchKernelGGL(colsum_kernel<bf16>, grid, block, 0, s, (const bf16*)in, out, R, C, ld, div, mod, rpb);
   else hipLaunchKernelGGL(colsum_kernel<float>, grid, block, 0, s, (const float*)in, out, R, C, ld, div, mod, rpb);
   return missm_check_launch("colsum");
+}
+
+extern "C" int missm_cast_weights_batched(const void* tiles, int ntiles, int dtype, void* stream) {
+  MISSM_CHECK_ARG(tiles && ntiles > 0, "cast_weights_batched: empty table");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == kBF16) hipLaunchKernelGGL(cast_weights_batched_kernel<bf16>, dim3(ntiles), dim3(256), 0, s, (const CastTile*)tiles);
+  else hipLaunchKernelGGL(cast_weights_batched_kernel<float>, dim3(ntiles), dim3(256), 0, s, (const CastTile*)tiles);
+  return missm_check_launch("cast_weights_batched");
 }
 
 extern "C" int missm_cast_weight(const float* src, void* dst, void* dst_t, int R, int C, int dtype, void* stream) {

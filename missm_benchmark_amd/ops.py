@@ -115,6 +115,25 @@ def cast_weight(src: torch.Tensor, dst: Optional[torch.Tensor], dst_t: Optional[
     _lib.call("missm_cast_weight", src.data_ptr(), _p(dst), _p(dst_t), R, Cn, dt(ref), _s())
 
 
+def build_cast_table(entries, device):
+    """entries: [(src fp32 [R,C], dst or None, dst_t or None)] -> device uint8 tensor of CastTile records + tile count"""
+    import numpy as np
+    rec = np.dtype([("src", "<u8"), ("dst", "<u8"), ("dst_t", "<u8"), ("R", "<i4"), ("C", "<i4"), ("r0", "<i4"), ("c0", "<i4")])
+    rows = []
+    for src, dst, dst_t in entries:
+        R, Cn = src.shape
+        for r0 in range(0, R, 64):
+            for c0 in range(0, Cn, 64):
+                rows.append((src.data_ptr(), 0 if dst is None else dst.data_ptr(), 0 if dst_t is None else dst_t.data_ptr(), R, Cn, r0, c0))
+    arr = np.array(rows, dtype=rec)
+    assert rec.itemsize == 40
+    return torch.from_numpy(arr.view(np.uint8).copy()).to(device), len(rows)
+
+
+def cast_weights_batched(table: torch.Tensor, ntiles: int, dtype_code: int):
+    _lib.call("missm_cast_weights_batched", table.data_ptr(), ntiles, dtype_code, _s())
+
+
 def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, *, add=None, add_div=1, add_mod=1, in_mul=1, in_off=None):
     _lib.call("missm_layernorm_fwd", x.data_ptr(), x.data_ptr() if add is not None else None, _p(add), add_div, add_mod, in_mul,
               _p(in_off), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), _p(mean), _p(rstd), rows, cols, float(eps), dt(y), _s())

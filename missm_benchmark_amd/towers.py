@@ -199,20 +199,21 @@ class ClipTower(nn.Module):
         return self._store.ensure_grad()
 
     def _refresh_shadows(self):
-        """(re)build the compute-dtype copies W [N,K] and W^T [K,N] of every GEMM weight block"""
+        """(re)build the compute-dtype copies W [N,K] and W^T [K,N] of every GEMM weight block - one launch per tower"""
         st = self._store
         T = self.compute_dtype
-        for key, b in self._mat_blocks.items():
-            K = st.index[b.items[0][0]][1]
-            n_out = sum(s[0] for _, s in b.items)
-            k_in = b.numel // n_out
-            src = st.block_view(b, st.master).view(n_out, k_in)
-            if key not in self._shadow:
+        if not self._shadow:
+            entries = []
+            for key, b in self._mat_blocks.items():
+                n_out = sum(s[0] for _, s in b.items)
+                k_in = b.numel // n_out
+                src = st.block_view(b, st.master).view(n_out, k_in)
                 w = src if T == torch.float32 else torch.empty(n_out, k_in, device=src.device, dtype=T)
                 wt = torch.empty(k_in, n_out, device=src.device, dtype=T)
                 self._shadow[key] = (w, wt)
-            w, wt = self._shadow[key]
-            ops.cast_weight(src, None if T == torch.float32 else w, wt)
+                entries.append((src, None if T == torch.float32 else w, wt))
+            self._cast_table, self._cast_tiles = ops.build_cast_table(entries, st.master.device)
+        ops.cast_weights_batched(self._cast_table, self._cast_tiles, ops.F32 if T == torch.float32 else ops.BF16)
         self._shadow_version = st.master._version
 
     def _ensure_ready(self):
