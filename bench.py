@@ -50,6 +50,16 @@ def parse():
     return ap.parse_args()
 
 
+def gemm_traffic():
+    """HBM-side bytes per GEMM launch from the committed PMC passes (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE doubled per
+    the gfx950 correction + WRITE_SIZE, separate rocprofv3 --pmc runs of this script with --serial-streams); None if absent."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        return {"bytes_per_launch": d["kernels"]["gemm"]["bytes_per_launch"], "unit": "B", "source": "profiles/r01_pmc_hbm_traffic.json"}
+    except Exception:
+        return None
+
+
 def workload_name(modalities, args) -> str:
     ms = set(modalities)
     if ms == set(MODALITIES):
@@ -228,7 +238,7 @@ def main():
         ach = flops / (ms * 1e-3) / 1e12
         roof = {"kernel": "gemm_kernel<bf16,TA,TB,128,VAR> (the MFMA GEMM behind every linear, dX and dW)" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
-                "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": None,
+                "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4), "traffic": gemm_traffic(),
                 "launches": len(prof), "avg_launch_us": round(ms * 1e3 / len(prof), 2),
                 "measured_on": "timed region (single stream)" if inline_prof else "single-stream replay of the same step after the timed region",
                 "gemm_ms_per_step": round(ms / (args.steps if inline_prof else 2), 2),
