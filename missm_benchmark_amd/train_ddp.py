@@ -1,0 +1,221 @@
+"""Drop-in for the reference's ``train_ddp.py`` training / validation loop on the MI355X hot path.
+
+Same CLI flags (reference train_ddp.py:19-47), same loop structure (:215-262), same ``evaluate`` contract
+(:91-135: no-grad forward, argmax / softmax, three ``all_gather``s, sklearn accuracy / macro-F1 / OvO AUC), same
+checkpoint dictionaries (:298-306, :320-323) and early stopping (:311-313).  What changes underneath:
+
+  * ``DistributedDataParallel`` + ``optim.Adam``  ->  ``engine.TrainEngine`` (flat-gradient RCCL all-reduce overlapped
+    with the hand-written backward, fused Adam);  ``nn.CrossEntropyLoss`` -> ``nn.HipCrossEntropyLoss``;
+  * the dataset loaders (``src/dataset/data_loader.py``) read private datasets and are out of scope: ``train`` takes any
+    iterable of ``(data, label, missing_index)`` batches shaped like the reference's (``data[m][k]`` tensors with the
+    extra singleton dim the reference squeezes at :224-227 are accepted); ``synthetic_loader`` builds one for smoke runs;
+  * checkpoints cannot be fetched by name (no network): see ``languagebind.LanguageBindModel.from_pretrained``.
+Distillation modes (MTD_stu / KL_stu / self_distill) need fusion heads that are queued.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+from typing import Dict, Iterable, Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch import nn
+
+from .engine import TrainEngine
+from .languagebind import LanguageBind, to_device
+from .nn import HipCrossEntropyLoss
+from .src.model.baseline import finetune_model
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser()
+    p.add_argument("--train_mode", type=str, default="classification")
+    p.add_argument("--datasetName", type=str, default="mvsa")
+    p.add_argument("--csv_path", type=str, default="")
+    p.add_argument("--modality_types", type=lambda s: s.split(","), default=["language", "image"])
+    p.add_argument("--train_missing", type=lambda s: s.lower() in ("1", "true", "yes"), default=False)
+    p.add_argument("--feature_dims", type=int, default=768)
+    p.add_argument("--fusion_type", type=str, default="sum")
+    p.add_argument("--fusion_dim", type=int, default=256)
+    p.add_argument("--dropout_prob", type=float, default=0.1)
+    p.add_argument("--num_workers", type=int, default=8)
+    p.add_argument("--batch_size", type=int, default=2)
+    p.add_argument("--num_epochs", type=int, default=50)
+    p.add_argument("--learning_rate", type=float, default=1e-4)
+    p.add_argument("--weight_decay", type=float, default=0)
+    p.add_argument("--patience", type=int, default=8)
+    p.add_argument("--seed", type=int, default=42)
+    p.add_argument("--save_path", type=str, default="checkpoints")
+    p.add_argument("--log_dir", type=str, default="logs")
+    return p.parse_args(argv)
+
+
+def set_seed(seed: int):
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def gather_tensor(tensor: torch.Tensor, n: int) -> torch.Tensor:
+    """train_ddp.py:64-67"""
+    if n == 1:
+        return tensor
+    out = [torch.zeros_like(tensor) for _ in range(n)]
+    dist.all_gather(out, tensor)
+    return torch.cat(out, dim=0)
+
+
+def reduce_tensor(tensor: torch.Tensor, n: int) -> torch.Tensor:
+    """train_ddp.py:57-61 (defined by the reference, never called there)"""
+    rt = tensor.clone()
+    if n > 1:
+        dist.all_reduce(rt, op=dist.ReduceOp.SUM)
+    return rt / n
+
+
+def get_criterion(args):
+    if args.fusion_type in ("MTD_stu", "KL_stu", "self_distill"):
+        raise NotImplementedError(f"{args.fusion_type}: distillation heads are queued (SURVEY.md 8f rank 2)")
+    return HipCrossEntropyLoss()
+
+
+def _prepare(data: Dict[str, Dict[str, torch.Tensor]], device):
+    out = {}
+    for k, v in data.items():
+        out[k] = to_device({i: j.squeeze(1) for i, j in v.items()}, device)      # train_ddp.py:224-227
+    return out
+
+
+def _metrics(labels, preds, probs):
+    from sklearn.metrics import accuracy_score, f1_score, roc_auc_score
+    m = {"accuracy": accuracy_score(labels, preds), "f1": f1_score(labels, preds, average="macro")}
+    try:
+        m["auc"] = roc_auc_score(labels, probs if probs.shape[1] > 2 else probs[:, 1], multi_class="ovo")
+    except ValueError:      # a class absent from this evaluation set
+        m["auc"] = float("nan")
+    return m
+
+
+def evaluate(model: nn.Module, dataloader: Iterable, criterion, world_size: int, device) -> Dict[str, float]:
+    """reference train_ddp.py:91-135"""
+    model.eval()
+    total, nb = 0.0, 0
+    probs, preds, labels_all = [], [], []
+    with torch.no_grad():
+        for data, label, missing_index in dataloader:
+            data = _prepare(data, device)
+            labels = (label["label"] if isinstance(label, dict) else label).to(device)
+            outputs = model(data, missing_index.to(device))
+            total += float(criterion(outputs, labels))
+            nb += 1
+            # softmax / argmax of a [B, C] logit block: host-side bookkeeping of the metrics, like the reference
+            p = torch.softmax(outputs.float(), dim=-1)
+            probs.append(gather_tensor(p, world_size).cpu().numpy())
+            preds.append(gather_tensor(outputs.argmax(dim=1), world_size).cpu().numpy())
+            labels_all.append(gather_tensor(labels, world_size).cpu().numpy())
+    out = _metrics(np.concatenate(labels_all), np.concatenate(preds), np.concatenate(probs))
+    out["loss"] = total / max(nb, 1)
+    return out
+
+
+def synthetic_loader(modality_types, batch_size: int, num_batches: int, num_classes: int, seed: int, *, image_size=224, frames=8,
+                     ctx=77, vocab=49408, missing_ratio: float = 0.0):
+    """A list of reference-shaped batches of random data (the real loaders are out of scope)."""
+    from .data import synth_missing_index, synth_text_batch
+    g = torch.Generator().manual_seed(seed)
+    batches = []
+    for b in range(num_batches):
+        data = {}
+        for m in modality_types:
+            if m == "language":
+                ids, mask = synth_text_batch(batch_size, ctx, seed * 1000 + b, vocab)
+                data[m] = {"input_ids": ids, "attention_mask": mask}
+            elif m == "video":
+                data[m] = {"pixel_values": torch.randn(batch_size, 3, frames, image_size, image_size, generator=g)}
+            else:
+                data[m] = {"pixel_values": torch.randn(batch_size, 3, image_size, image_size, generator=g)}
+        labels = torch.randint(0, num_classes, (batch_size,), generator=g)
+        missing = synth_missing_index(batch_size, modality_types, missing_ratio, seed + b) if missing_ratio > 0 else \
+            torch.zeros(batch_size, dtype=torch.int64)
+        batches.append((data, {"label": labels}, missing))
+    return batches
+
+
+def train(args, train_loader: Iterable, valid_loader: Iterable, output_dims: int, encoder_model: Optional[nn.Module] = None,
+          compute_dtype: torch.dtype = torch.bfloat16, log=print):
+    """reference train_ddp.py:138-329 with the loaders injected"""
+    set_seed(args.seed)
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    device = f"cuda:{local_rank}"
+    torch.cuda.set_device(local_rank)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and not dist.is_initialized():
+        dist.init_process_group(backend="nccl", init_method="env://")
+    world_size = _world()
+    experiment = f"{args.datasetName}_{args.fusion_type}"
+    save_path = os.path.join("./experiments", experiment, args.save_path)
+    final_model_path = "./final_model"
+    if local_rank == 0:
+        os.makedirs(save_path, exist_ok=True)
+        os.makedirs(final_model_path, exist_ok=True)
+    if encoder_model is None:
+        clip_type = {m: f"LanguageBind_{m.capitalize()}" for m in args.modality_types if m != "language"}
+        encoder_model = LanguageBind(clip_type=clip_type, cache_dir="./cache_dir", compute_dtype=compute_dtype, seed=args.seed)
+    model = finetune_model(args, output_dims, encoder_model).to(device)
+    criterion = get_criterion(args)
+    engine = TrainEngine(model, lr=args.learning_rate, weight_decay=args.weight_decay)
+    best, best_epoch, patience, lr_bad = 0.0, 0, 0, 0
+    for epoch in range(args.num_epochs):
+        model.train()
+        train_loss, nb = 0.0, 0
+        for data, label, missing_index in train_loader:
+            engine.zero_grad()
+            data = _prepare(data, device)
+            labels = (label["label"] if isinstance(label, dict) else label).to(device)
+            outputs = model(data, missing_index.to(device))
+            loss = criterion(outputs, labels)
+            loss.backward()
+            engine.step()
+            train_loss += float(loss.detach())      # the reference also syncs on loss.item() every step (:261)
+            nb += 1
+        val = evaluate(model, valid_loader, criterion, world_size, device)
+        if local_rank == 0:
+            log(f"Epoch {epoch + 1}/{args.num_epochs}  train loss {train_loss / max(nb, 1):.4f}  val loss {val['loss']:.4f}  "
+                f"acc {val['accuracy']:.4f}  f1 {val['f1']:.4f}  auc {val['auc']:.4f}")
+        # ReduceLROnPlateau(mode='max', factor=0.1, patience=3) on validation accuracy (:206,286)
+        if val["accuracy"] > best:
+            best, best_epoch, patience, lr_bad = val["accuracy"], epoch, 0, 0
+            if local_rank == 0:
+                sd = {"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}   # DDP-prefixed like :302
+                torch.save({"epoch": epoch, "model_state_dict": sd, "optimizer_state_dict": {"step": engine.step_count},
+                            "val_metrics": val, "args": vars(args)}, os.path.join(save_path, "best_model.pth"))
+        else:
+            patience += 1
+            lr_bad += 1
+            if lr_bad > 3:
+                engine.lr *= 0.1
+                lr_bad = 0
+        if patience >= args.patience:
+            break
+    if world_size > 1:
+        dist.barrier()
+    ckpt = torch.load(os.path.join(save_path, "best_model.pth"), map_location="cpu", weights_only=False)
+    model.load_state_dict({k[len("module."):]: v for k, v in ckpt["model_state_dict"].items()})
+    model.eval()
+    if local_rank == 0:
+        torch.save({"model_state_dict": model.state_dict()}, os.path.join(final_model_path, f"{experiment}.pth"))
+    return model
+
+
+if __name__ == "__main__":
+    a = parse_args()
+    mt = a.modality_types
+    tl = synthetic_loader(mt, a.batch_size, 4, 3, a.seed)
+    vl = synthetic_loader(mt, a.batch_size, 2, 3, a.seed + 1)
+    train(a, tl, vl, 3)
+    print("Training completed!")

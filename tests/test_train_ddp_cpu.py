@@ -1,0 +1,59 @@
+"""Host logic of the train_ddp drop-in that needs no GPU: CLI surface, batch shapes, metrics, world-2 gather."""
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from missm_benchmark_amd import train_ddp as T
+
+
+def test_cli_defaults_match_reference():
+    a = T.parse_args([])
+    # reference train_ddp.py:19-47
+    assert (a.train_mode, a.fusion_type, a.feature_dims, a.fusion_dim) == ("classification", "sum", 768, 256)
+    assert (a.batch_size, a.num_epochs, a.learning_rate, a.weight_decay, a.patience, a.seed) == (2, 50, 1e-4, 0, 8, 42)
+    assert T.parse_args(["--modality_types", "language,video"]).modality_types == ["language", "video"]
+    assert T.parse_args(["--train_missing", "True"]).train_missing is True
+
+
+def test_synthetic_loader_shapes():
+    (data, label, miss), = T.synthetic_loader(["language", "video", "image"], 3, 1, 4, 0, image_size=32, frames=2, ctx=16, vocab=100,
+                                              missing_ratio=0.5)
+    assert data["language"]["input_ids"].shape == (3, 16) and data["language"]["attention_mask"].shape == (3, 16)
+    assert data["video"]["pixel_values"].shape == (3, 3, 2, 32, 32) and data["image"]["pixel_values"].shape == (3, 3, 32, 32)
+    assert label["label"].shape == (3,) and miss.shape == (3,) and miss.dtype == torch.int64
+
+
+def test_prepare_squeezes_loader_dim():
+    d = T._prepare({"image": {"pixel_values": torch.zeros(2, 1, 3, 8, 8)}, "video": {"pixel_values": torch.zeros(2, 3, 4, 8, 8)},
+                    "language": {"input_ids": torch.zeros(2, 1, 5, dtype=torch.long)}}, "cpu")
+    assert d["image"]["pixel_values"].shape == (2, 3, 8, 8) and d["video"]["pixel_values"].shape == (2, 3, 4, 8, 8)
+    assert d["language"]["input_ids"].shape == (2, 5)
+
+
+def test_metrics():
+    y = np.array([0, 1, 2, 1]); p = np.array([0, 1, 1, 1])
+    pr = np.array([[.8, .1, .1], [.1, .8, .1], [.2, .5, .3], [.1, .7, .2]])
+    m = T._metrics(y, p, pr)
+    assert m["accuracy"] == 0.75 and 0 < m["f1"] < 1 and 0.5 < m["auc"] <= 1.0
+    assert np.isnan(T._metrics(np.array([0, 0]), np.array([0, 0]), pr[:2])["auc"])
+
+
+def _gather_worker(rank, port, q):
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    g = T.gather_tensor(torch.full((2, 3), float(rank)), 2)
+    r = T.reduce_tensor(torch.tensor([float(rank + 1)]), 2)
+    q.put((rank, g.tolist(), float(r)))
+    dist.destroy_process_group()
+
+
+def test_gather_and_reduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_gather_worker, args=(r, 29653, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = [q.get(timeout=120) for _ in ps]
+    [p.join(60) for p in ps]
+    for _, g, r in res:
+        assert g == [[0.0] * 3] * 2 + [[1.0] * 3] * 2 and r == 1.5
+    assert T.gather_tensor(torch.ones(2), 1).tolist() == [1.0, 1.0]

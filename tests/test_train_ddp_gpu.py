@@ -1,0 +1,84 @@
+"""train_ddp drop-in on the GPU: the validation pass (no-grad forward + metrics, reference train_ddp.py:91-135) against
+the CPU oracle, and the epoch loop (train -> evaluate -> checkpoint -> reload) on synthetic reference-shaped batches."""
+import os
+import types
+
+import numpy as np
+import pytest
+import torch
+
+import missm_oracle as O
+from test_towers_gpu import _oracle_of, _tiny_model, pkg, rel  # noqa: F401  (pkg is a fixture)
+
+pytestmark = pytest.mark.gpu
+
+
+def _batches(n, B, seed, missing=True):
+    out = []
+    for b in range(n):
+        g = torch.Generator().manual_seed(seed + b)
+        ids, mask = O.synth_text_batch(B, 16, seed + b, vocab=512)
+        data = {"language": {"input_ids": ids.unsqueeze(1), "attention_mask": mask.unsqueeze(1)},   # loader-style extra dim
+                "video": {"pixel_values": torch.randn(B, 1, 3, 4, 32, 32, generator=g)},
+                "image": {"pixel_values": torch.randn(B, 1, 3, 32, 32, generator=g)}}
+        miss = torch.randint(0, 5, (B,), generator=g) if missing else torch.zeros(B, dtype=torch.int64)
+        miss[miss == 3] = 0
+        out.append((data, {"label": torch.randint(0, 5, (B,), generator=g)}, miss))
+    return out
+
+
+def test_evaluate_matches_oracle(pkg):
+    from missm_benchmark_amd import train_ddp as T
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    model, cfgs, tcfg, args = _tiny_model(pkg, torch.float32)
+    tp, tc, proj, scales, fp = _oracle_of(model, cfgs, tcfg, args)
+    model = model.cuda()
+    batches = _batches(3, 6, 11)
+    got = T.evaluate(model, batches, HipCrossEntropyLoss(), 1, "cuda:0")
+    losses, preds, labels, probs = [], [], [], []
+    with torch.no_grad():
+        for data, label, miss in batches:
+            d = {m: {k: v.squeeze(1) for k, v in x.items()} for m, x in data.items()}
+            logits, _ = O.finetune_forward(d, miss, tp, tc, proj, scales, fp, args.modality_types)
+            losses.append(float(O.cross_entropy(logits, label["label"])))
+            preds.append(logits.argmax(1).numpy())
+            probs.append(torch.softmax(logits, -1).numpy())
+            labels.append(label["label"].numpy())
+    want = T._metrics(np.concatenate(labels), np.concatenate(preds), np.concatenate(probs))
+    assert abs(got["loss"] - sum(losses) / 3) < 1e-3
+    assert got["accuracy"] == want["accuracy"] and abs(got["f1"] - want["f1"]) < 1e-9
+    assert (np.isnan(got["auc"]) and np.isnan(want["auc"])) or abs(got["auc"] - want["auc"]) < 1e-3
+    assert not model.training
+
+
+def test_no_grad_forward_equals_training_forward(pkg):
+    model, *_ = _tiny_model(pkg, torch.bfloat16)
+    model = model.cuda()
+    (data, _, miss), = _batches(1, 4, 3)
+    d = {m: {k: v.squeeze(1).cuda() for k, v in x.items()} for m, x in data.items()}
+    a = model(d, miss.cuda())
+    with torch.no_grad():
+        b = model(d, miss.cuda())
+    assert not b.requires_grad and torch.equal(a.detach(), b)
+
+
+def test_train_loop_checkpoints_and_learns(pkg, tmp_path, monkeypatch):
+    from missm_benchmark_amd import train_ddp as T
+    monkeypatch.chdir(tmp_path)
+    model, cfgs, tcfg, margs = _tiny_model(pkg, torch.float32)
+    args = T.parse_args(["--modality_types", "language,video,image", "--feature_dims", "48", "--fusion_dim", "32", "--dropout_prob", "0.0",
+                         "--num_epochs", "3", "--learning_rate", "1e-3", "--datasetName", "synthetic", "--patience", "8"])
+    assert args.modality_types == ["language", "video", "image"] and args.fusion_type == "sum"
+    tl, vl = _batches(4, 6, 100), _batches(4, 6, 100)     # validate on the training batches: accuracy must rise
+    lines = []
+    out = T.train(args, tl, vl, 5, encoder_model=model.encoder, compute_dtype=torch.float32, log=lines.append)
+    assert len(lines) == 3 and all("val loss" in s for s in lines)
+    first, last = (float(s.split("train loss")[1].split()[0]) for s in (lines[0], lines[-1]))
+    assert last < first
+    ck = torch.load(tmp_path / "experiments" / "synthetic_sum" / "checkpoints" / "best_model.pth", weights_only=False)
+    assert set(ck) >= {"epoch", "model_state_dict", "optimizer_state_dict", "val_metrics", "args"}
+    assert all(k.startswith("module.") for k in ck["model_state_dict"])
+    final = torch.load(tmp_path / "final_model" / "synthetic_sum.pth", weights_only=False)["model_state_dict"]
+    assert set(final) == set(out.state_dict())
+    for k, v in out.state_dict().items():
+        assert torch.equal(v.cpu(), ck["model_state_dict"]["module." + k]), k
