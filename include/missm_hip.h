@@ -57,8 +57,10 @@ int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, in
  *   trans_a == 0: A is [M,K] (k contiguous)      trans_a == 1: A is [K,M] (stored as produced, e.g. dY for dW = dY^T X)
  *   trans_b == 0: B is [N,K] (k contiguous)      trans_b == 1: B is [K,N] (e.g. the weight itself for dX = dY W)
  * so weight and input gradients read activations / weights where they lie - no transposed copies.  (trans_a, trans_b) in
- * {(0,0), (0,1), (1,1)}.  splitk: 1 = off, 0 = auto, > 1 = number of K slices whose partial products are atomically added
- * into a ZERO-INITIALISED fp32 C (weight gradients: tiny output, huge K).  colsum_a (trans_a only, optional): colsum_a[m] +=
+ * {(0,0), (0,1), (1,1)}.  splitk: 1 = off, 0 = auto (fp32 outputs whose tile grid cannot fill the chip: weight gradients -
+ * tiny output, huge K), > 1 = number of K slices.  The slices park their partial tiles in a per-stream workspace the library
+ * owns and a second kernel sums them in slice order (no atomics, bit-reproducible; alpha / bias / accumulate apply there);
+ * the workspace is allocated / grown on first use, which synchronises `stream` once.  colsum_a (trans_a only, optional): colsum_a[m] +=
  * sum_k A[k][m] - the bias gradient rides in the weight-gradient GEMM as a ones-column (caller zeroes it). */
 int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a, int trans_b,
                float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out, int ldaux, int act,
@@ -67,6 +69,8 @@ int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int l
 /* Diagnostic only: when set (device pointer to 8 x uint64 per workgroup), the next GEMM launches record per-workgroup
  * {start, first tile landed, main loop end, end, HW_ID, stores issued} stamps of the 100 MHz clock; NULL switches it off. */
 void missm_gemm_set_debug_buffer(void* stamps);
+/* Frees every split-K workspace (device-synchronises); they are re-created on demand. */
+void missm_gemm_release_workspaces(void);
 
 /* out[C, ldo] = in[R, C]^T zero-padded to ldo columns; optional colsum[C] += column sums (bias gradient). */
 int missm_transpose_pad(const void* in, void* out, int R, int C, int ld, int ldo, float* colsum, int dtype, void* stream);

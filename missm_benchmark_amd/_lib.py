@@ -41,7 +41,7 @@ SIGNATURES = {
     "missm_adam_step": [P, P, P, P, L, I, F, F, F, F, F, F, P],
 }
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
-         "missm_gemm_set_debug_buffer": ([P], None)}
+         "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
 _lib = None
 

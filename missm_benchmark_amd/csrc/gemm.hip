@@ -14,6 +14,8 @@
 #include "mma.h"
 #include "missm_internal.h"
 #include <stdlib.h>
+#include <mutex>
+#include <unordered_map>
 
 namespace missm {
 
@@ -34,7 +36,8 @@ struct GemmArgs {
   int accumulate;         // out_f32 only: C += result
   int tiles_m, tiles_n;
   int vec_ok;             // ldc/ldaux/pointers allow 16-byte (fp32) / 8-byte (bf16) vector epilogue accesses
-  int splitk, k_per_split;  // splitk > 1: each K slice atomically adds its partial into the (zeroed) fp32 C
+  int splitk, k_per_split;  // splitk > 1: K slices; partial tiles go to `ws`, splitk_reduce_kernel sums them into C
+  float* ws;                // split-K workspace: [splitk][tiles][16][256] float4 partial accumulators (register order)
   unsigned long long* dbg;  // diagnostic builds only: per-workgroup {start, loop start, loop end, end, hw id} stamps (100 MHz clock)
   int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
@@ -74,6 +77,17 @@ template <int COLS> struct KMajorFrag<float, COLS> {
   }
 };
 
+// sum of the k values one lane holds in an operand fragment (bias gradient riding in the dW GEMM): packed bf16 dot
+// products against (1, 1) on the otherwise idle VALU instead of extra MFMAs against a ones-column
+__device__ __forceinline__ float frag_sum(bf16x8 f, float s) {
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+  const bf16x2 one = {(__bf16)1.0f, (__bf16)1.0f};
+#pragma unroll
+  for (int p = 0; p < 4; ++p) s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{f[2 * p], f[2 * p + 1]}, one, s, false);
+  return s;
+}
+__device__ __forceinline__ float frag_sum(f32x4 f, float s) { return s + ((f[0] + f[1]) + (f[2] + f[3])); }
+
 // Grouped tile order: consecutive logical ids walk DOWN a group of `gm` tile rows before moving to the next tile column,
 // so the ~64 workgroups resident on one XCD cover a gm x (64/gm) patch of tiles and share gm A panels and 64/gm B panels
 // in that XCD's 4 MiB L2, instead of one A panel and every B panel (fc1's 4.7 MB weight does not fit next to A).
@@ -106,7 +120,6 @@ __device__ __forceinline__ void epi_finish(const GemmArgs& g, float x, size_t of
   }
   if (g.out_f32) {
     float* c = static_cast<float*>(g.C) + off;
-    if (g.splitk > 1) { atomicAdd(c, x); return; }
     if (g.resid) x += g.resid[off];
     if (g.accumulate) x += *c;
     *c = x;
@@ -156,6 +169,64 @@ __device__ __forceinline__ void epilogue_generic(const GemmArgs& g, f32x4 (&acc)
   }
 }
 
+// Split-K without atomics.  fp32 atomics retire one element per L2 channel per clock: a 128x128 tile of them cost 21-30 us,
+// more than the main loop of a K = 6304 weight gradient.  (Also measured: the slices meeting inside the GEMM kernel, last
+// arriver sums - an agent-scope fence flushes / invalidates the whole XCD L2, 37-85 us per tile; with sc1 stores / loads
+// instead the one finishing workgroup reads splitk x 64 KiB serially at memory latency, 15-39 us.)  So every K slice parks
+// its accumulators in the per-stream workspace in REGISTER order - thread t, vector v -> float4 #(v*256 + t): coalesced, and
+// identical in every slice - and a second, chip-wide kernel sums the slices in slice order (bit-reproducible) and applies
+// alpha / bias / accumulate.  One workgroup per (tile, i): thread t owns the same (row, col) set the GEMM thread t owned.
+template <bool TB>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+  const int ntiles = g.tiles_m * g.tiles_n;
+  const int tile = blockIdx.x >> 2, i = blockIdx.x & 3;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
+  int tm, tn;
+  tile_of(xcd_remap(tile, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  const int mw = tm * BM + (wave >> 1) * 64, nw = tn * BN + (wave & 1) * 64;
+  const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + (size_t)tile * 4096 + (i * 4) * 256 + tid;
+  f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int sl = 0; sl < g.splitk; ++sl, p += (size_t)ntiles * 4096) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) a[j] += __builtin_nontemporal_load(p + j * 256);
+  }
+  float* C = static_cast<float*>(g.C);
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = mw + i * 16 + lg * 4 + r;
+    if (row >= g.M) continue;
+    if constexpr (TB) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = nw + j * 16 + li;
+        if (col >= g.N) continue;
+        float x = a[j][r] * g.alpha + (g.bias ? g.bias[col] : 0.f);
+        float* c = C + (size_t)row * g.ldc + col;
+        if (g.accumulate) x += *c;
+        *c = x;
+      }
+    } else {
+      const int col = nw + li * 4;
+      float* c = C + (size_t)row * g.ldc + col;
+      if (col + 3 < g.N && g.vec_ok) {
+        f32x4 x = {a[0][r], a[1][r], a[2][r], a[3][r]};
+        x *= g.alpha;
+        if (g.bias) x += load4(g.bias + col);
+        if (g.accumulate) x += load4(c);
+        store4(c, x);
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (col + j < g.N) {
+            float x = a[j][r] * g.alpha + (g.bias ? g.bias[col + j] : 0.f);
+            if (g.accumulate) x += c[j];
+            c[j] = x;
+          }
+      }
+    }
+  }
+}
+
 template <typename T, bool TB>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane,
                                               f32x4 bias4, float* wave_lds) {
@@ -163,22 +234,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
   const bool first_split = split == 0;
   if constexpr (TB) {
     // (register arrays must only ever be indexed with compile-time constants: a rolled loop here sends `acc` to scratch)
-    const bool atomic = g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
+    const bool plain_f = g.out_f32 && g.act == MISSM_ACT_NONE && !g.resid && !g.accumulate;   // weight gradients
     const bool plain_t = !g.out_f32 && g.act == MISSM_ACT_NONE;
-    if (!atomic && !plain_t) { epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds); return; }
+    if (!plain_f && !plain_t) { epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds); return; }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = nw + j * 16 + li;
       if (col >= g.N) continue;
       const float bv = (g.bias && first_split) ? g.bias[col] : 0.f;
-      if (atomic) {                       // weight gradients: split-K partials
+      if (plain_f) {
         float* C = static_cast<float*>(g.C);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = mw + i * 16 + lg * 4 + r;
-            if (row < g.M) atomicAdd(C + (size_t)row * g.ldc + col, acc[i][j][r] * g.alpha + bv);
+            if (row < g.M) C[(size_t)row * g.ldc + col] = acc[i][j][r] * g.alpha + bv;
           }
       } else if (plain_t) {
         T* C = static_cast<T*>(g.C);
@@ -197,9 +268,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
     if (nw >= g.N) return;
     const float alpha = g.alpha;
     // wave-uniform decisions only: the generic path exchanges data between the lanes of the wave through LDS
-    const bool vec = (nw + 64 <= g.N) && g.vec_ok && g.splitk == 1 && g.act != MISSM_ACT_RELU && g.act != MISSM_ACT_GELU &&
+    const bool vec = (nw + 64 <= g.N) && g.vec_ok && g.act != MISSM_ACT_RELU && g.act != MISSM_ACT_GELU &&
                      g.act != MISSM_ACT_DGELU && !g.accumulate;
-    const bool vec_atomic = (nw + 64 <= g.N) && g.out_f32 && g.splitk > 1 && g.act == MISSM_ACT_NONE;
     // value of (tile i, register r): 4 consecutive columns
 #define MISSM_EPI_LOOP(BODY)                                                      \
     _Pragma("unroll") for (int i = 0; i < 4; ++i) {                               \
@@ -232,9 +302,6 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
       float* C = static_cast<float*>(g.C);
       const float* R = g.resid;
       MISSM_EPI_LOOP(if (R) { const f32x4 q = load4(R + off); v += q; } store4(C + off, v);)
-    } else if (vec_atomic) {                                            // split-K partials of an NT product
-      float* C = static_cast<float*>(g.C);
-      MISSM_EPI_LOOP(atomicAdd(C + off, v[0]); atomicAdd(C + off + 1, v[1]); atomicAdd(C + off + 2, v[2]); atomicAdd(C + off + 3, v[3]);)
     } else {                                                            // ragged edges, rare activations, accumulate
       epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds);
     }
@@ -342,20 +409,17 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // bias gradient: for the first column of tiles, waves with wn == 0 also multiply their A fragments by a ones-column
+  // bias gradient: in the first column of tiles, waves with wn == 0 also add up the A fragments they hold (VALU, beside the
+  // MFMAs).  Measured alternatives: MFMAs against a ones-column cost those workgroups +25 % and they set the kernel's span;
+  // sharing that work between all tiles of a tile row multiplies the atomics on the same 128 addresses (slower overall).
   const bool do_cs = TA && g.colsum_a != nullptr && tn == 0 && wn == 0;
-  Frag ones;
-#pragma unroll
-  for (int j = 0; j < M_::KPL; ++j) ones[j] = from_f32<T>(1.0f);
-  f32x4 accb[4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) accb[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float accb[4] = {0.f, 0.f, 0.f, 0.f};   // lane (li, lg): partial sum of row 16 i + li over the k values of lane group lg
 
   const int nk = (kend - kbeg + BK - 1) / BK;
   if (nk <= 0) return;
   unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;
   if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
-  const f32x4 bias4 = prefetch_bias(g, n0 + wn * 64, split, lane);
+  const f32x4 bias4 = prefetch_bias(g, n0 + wn * 64, 0, lane);
   stage(0, kbeg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -366,15 +430,21 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     if (kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);   // next tile lands in the other buffer under this tile's MFMAs
     const char* la = ldsA + buf * TILE_BYTES;
     const char* lb = ldsB + buf * TILE_BYTES;
-    if constexpr (VAR == 2 && !TA && !TB) {
+    if constexpr (VAR == 2) {
       // all fragments of the K tile are requested up front; MFMAs of step 0 start as soon as ITS fragments are back
       Frag fa[KSTEPS][4], fb[KSTEPS][4];
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) fa[ks][i] = lds_frag<T>(la, kswz<RBK>(wm * 64 + i * 16 + li, ks * 4 + lg));
+        for (int i = 0; i < 4; ++i) {
+          if constexpr (!TA) fa[ks][i] = lds_frag<T>(la, kswz<RBK>(wm * 64 + i * 16 + li, ks * 4 + lg));
+          else fa[ks][i] = KMajorFrag<T, 128>::load(la, ks, wm * 64 + i * 16, lane);
+        }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) fb[ks][j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, ks * 4 + lg));
+        for (int j = 0; j < 4; ++j) {
+          if constexpr (!TB) fb[ks][j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, ks * 4 + lg));
+          else fb[ks][j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
+        }
       }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -383,6 +453,14 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[ks][i], fb[ks][j], acc[i][j]);
+      if constexpr (TA) {
+        if (do_cs) {
+#pragma unroll
+          for (int ks = 0; ks < KSTEPS; ++ks)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) accb[i] = frag_sum(fa[ks][i], accb[i]);
+        }
+      }
       __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
@@ -408,7 +486,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
       if constexpr (TA) {
         if (do_cs) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) accb[i] = M_::step(fa[i], ones, accb[i]);
+          for (int i = 0; i < 4; ++i) accb[i] = frag_sum(fa[i], accb[i]);
         }
       }
     }
@@ -417,19 +495,26 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     __syncthreads();
   }
   if constexpr (TA) {
-    if (do_cs && li == 0) {   // every column of accb holds the row sums; lanes with li == 0 publish rows 4*lg + r
+    if (do_cs) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int m = m0 + wm * 64 + i * 16 + lg * 4 + r;
-          if (m < g.M) atomicAdd(g.colsum_a + m, accb[i][r]);
-        }
+      for (int i = 0; i < 4; ++i) {
+        float v = accb[i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int m = m0 + wm * 64 + i * 16 + li;
+        if (lg == 0 && m < g.M) atomicAdd(g.colsum_a + m, v);
+      }
     }
   }
 
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
-  gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, split, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384));
+  if (g.splitk > 1) {   // K slice: park the partial tile for splitk_reduce_kernel
+    f32x4* mine = reinterpret_cast<f32x4*>(g.ws) + ((size_t)split * ntiles + (bid - split * ntiles)) * 4096 + tid;
+#pragma unroll
+    for (int v = 0; v < 16; ++v) mine[v * 256] = acc[v >> 2][v & 3];
+  } else {
+    gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, 0, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384));
+  }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -595,6 +680,36 @@ using namespace missm;
 static unsigned long long* missm_gemm_debug_buffer = nullptr;
 extern "C" void missm_gemm_set_debug_buffer(void* p) { missm_gemm_debug_buffer = static_cast<unsigned long long*>(p); }
 
+// Split-K workspaces: one per stream (launches on a stream are ordered, so consecutive split-K GEMMs may share one; GEMMs on
+// different streams run concurrently and must not).  Grown on demand - growth synchronises that stream once, during warm-up.
+namespace {
+struct SplitKWs { float* ws = nullptr; size_t bytes = 0; };
+std::mutex g_ws_mu;
+std::unordered_map<void*, SplitKWs> g_ws;
+
+int splitk_workspace(void* stream, size_t bytes, float** ws) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  SplitKWs& w = g_ws[stream];
+  if (w.bytes < bytes) {
+    if (hipStreamSynchronize(static_cast<hipStream_t>(stream)) != hipSuccess) return 1;
+    if (w.ws) (void)hipFree(w.ws);
+    w = SplitKWs();
+    const size_t nb = bytes < (size_t(32) << 20) ? (size_t(32) << 20) : bytes;
+    if (hipMalloc(reinterpret_cast<void**>(&w.ws), nb) != hipSuccess) { w = SplitKWs(); return 1; }
+    w.bytes = nb;
+  }
+  *ws = w.ws;
+  return 0;
+}
+}  // namespace
+
+extern "C" void missm_gemm_release_workspaces(void) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  (void)hipDeviceSynchronize();
+  for (auto& kv : g_ws) if (kv.second.ws) (void)hipFree(kv.second.ws);
+  g_ws.clear();
+}
+
 extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                           int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
                           int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream) {
@@ -629,19 +744,25 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
     // Measured (dW shapes, tiles x splits): 144x3 = 432 -> 427-596 TFLOP/s, 144x4 = 576 -> 280-420 (a second, nearly empty
     // round), 36x12 -> 506 vs 36x8 -> 379; fewer splits also means fewer fp32 atomics (1.3 TB/s chip-wide).
     splitk = 1;
-    if (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE && tiles < fill) {
+    if (out_f32 && !resid && act == MISSM_ACT_NONE && tiles < fill) {
       splitk = fill / tiles;
       const int maxs = K / (4 * bk);
       if (splitk > maxs) splitk = maxs;
       if (splitk < 1) splitk = 1;
     }
   }
-  MISSM_CHECK_ARG(splitk == 1 || (out_f32 && !resid && !accumulate && act == MISSM_ACT_NONE),
-                  "gemm: split-K needs a zero-initialised fp32 output and no epilogue");
+  MISSM_CHECK_ARG(splitk == 1 || (out_f32 && !resid && act == MISSM_ACT_NONE), "gemm: split-K needs an fp32 output and no activation / residual");
   int kps = (K + splitk - 1) / splitk;
   kps = (kps + bk - 1) / bk * bk;
   splitk = (K + kps - 1) / kps;
   g.splitk = splitk; g.k_per_split = kps;
+  g.ws = nullptr;
+  if (splitk > 1) {
+    if (splitk_workspace(stream, (size_t)splitk * tiles * (BM * BN * sizeof(float)), &g.ws)) {
+      missm_set_error("gemm: cannot allocate the split-K workspace");
+      return MISSM_ERR_LAUNCH;
+    }
+  }
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
@@ -664,6 +785,10 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
     else MISSM_GEMM_LAUNCH(float, true, true);
   }
 #undef MISSM_GEMM_LAUNCH
+  if (splitk > 1) {
+    if (trans_b) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(tiles * 4), block, 0, s, g);
+    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(tiles * 4), block, 0, s, g);
+  }
   return missm_check_launch("gemm");
 }
 

@@ -52,7 +52,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
          splitk: int = 1, colsum_a=None, M=None, N=None, K=None):
     """out[M,N] = alpha * op(a) @ op(b) (+bias) -> act (+resid).
     a is [M,K] (or [K,M] with trans_a); b is [N,K] (or [K,N] with trans_b); out is the operand dtype or fp32.
-    splitk: 1 off, 0 auto, >1 slices (needs a zeroed fp32 ``out``)."""
+    splitk: 1 off, 0 auto, >1 K slices (fp32 ``out``; slices meet in a library-owned workspace, no atomics)."""
     _req(a, "gemm a"); _req(b, "gemm b"); _req(out, "gemm out")
     if a.dtype != b.dtype:
         raise _lib.MissmError("gemm: operand dtypes differ")
