@@ -427,7 +427,11 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);   // next tile lands in the other buffer under this tile's MFMAs
+    // The next tile lands in the other buffer under this tile's MFMAs.  With a k-major operand the LDS-DMA is issued AFTER
+    // the fragment reads: the compiler cannot see that ds_read_b64_tr_b16 (an intrinsic without memory operands) does not
+    // alias the DMA's LDS writes and would put s_waitcnt vmcnt(0) - the whole global-load latency - in front of the reads.
+    constexpr bool STAGE_LATE = VAR == 2 && (TA || TB);
+    if (!STAGE_LATE && kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
     const char* la = ldsA + buf * TILE_BYTES;
     const char* lb = ldsB + buf * TILE_BYTES;
     if constexpr (VAR == 2) {
@@ -446,6 +450,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
           else fb[ks][j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
         }
       }
+      if (STAGE_LATE && kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
@@ -768,7 +773,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
-  const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 1 : (K > 1024 ? 2 : 1));
+  const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 2 : (K > 1024 ? 2 : 1));
 #define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
   do {                                                                                                     \
     if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 0, s, g);          \
