@@ -227,9 +227,15 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+// raw pre-activation values (4 consecutive columns of one row) fetched before the main loop for the backward-through-
+// activation epilogue: 16 dependent 8-byte loads per lane otherwise sit, latency exposed, between the last MFMA and the stores
+template <typename T> struct AuxPre { static constexpr bool ok = false; using V = int; };
+template <> struct AuxPre<bf16> { static constexpr bool ok = true; using V = bf16x4; };
+
 template <typename T, bool TB>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane,
-                                              f32x4 bias4, float* wave_lds) {
+                                              f32x4 bias4, float* wave_lds, const typename AuxPre<T>::V (&upre)[4][4],
+                                              bool have_upre) {
   const int li = lane & 15, lg = lane >> 4;
   const bool first_split = split == 0;
   if constexpr (TB) {
@@ -295,6 +301,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
     } else if (vec && !g.out_f32 && g.act == MISSM_ACT_DQGELU) {        // backward through the activation
       T* C = static_cast<T*>(g.C);
       const T* U = static_cast<const T*>(g.aux_in);
+      if constexpr (AuxPre<T>::ok) {
+        if (have_upre) {
+          MISSM_EPI_LOOP(v[0] *= quick_gelu_grad((float)upre[i][r][0]); v[1] *= quick_gelu_grad((float)upre[i][r][1]);
+                         v[2] *= quick_gelu_grad((float)upre[i][r][2]); v[3] *= quick_gelu_grad((float)upre[i][r][3]);
+                         store4(C + off, v);)
+          return;
+        }
+      }
       MISSM_EPI_LOOP(const f32x4 u = load4(U + (size_t)row * g.ldaux + col);
                      v[0] *= quick_gelu_grad(u[0]); v[1] *= quick_gelu_grad(u[1]); v[2] *= quick_gelu_grad(u[2]);
                      v[3] *= quick_gelu_grad(u[3]); store4(C + off, v);)
@@ -420,6 +434,22 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;
   if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
   const f32x4 bias4 = prefetch_bias(g, n0 + wn * 64, 0, lane);
+  typename AuxPre<T>::V upre[4][4];
+  bool have_upre = false;
+  if constexpr (AuxPre<T>::ok && !TB) {
+    const int nw_ = n0 + wn * 64;
+    have_upre = g.act == MISSM_ACT_DQGELU && !g.out_f32 && g.vec_ok && !g.accumulate && nw_ + 64 <= g.N && g.splitk == 1;
+    if (have_upre) {
+      const T* U = static_cast<const T*>(g.aux_in) + nw_ + li * 4;
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + wm * 64 + i * 16 + lg * 4 + r, g.M - 1);
+          upre[i][r] = *reinterpret_cast<const bf16x4*>(U + (size_t)row * g.ldaux);
+        }
+    }
+  }
   stage(0, kbeg);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -518,7 +548,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 #pragma unroll
     for (int v = 0; v < 16; ++v) mine[v * 256] = acc[v >> 2][v & 3];
   } else {
-    gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, 0, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384));
+    gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, 0, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384), upre, have_upre);
   }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
