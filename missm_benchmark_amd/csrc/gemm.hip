@@ -423,10 +423,18 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // bias gradient: in the first column of tiles, waves with wn == 0 also add up the A fragments they hold (VALU, beside the
-  // MFMAs).  Measured alternatives: MFMAs against a ones-column cost those workgroups +25 % and they set the kernel's span;
-  // sharing that work between all tiles of a tile row multiplies the atomics on the same 128 addresses (slower overall).
-  const bool do_cs = TA && g.colsum_a != nullptr && tn == 0 && wn == 0;
+  // bias gradient: waves also add up A fragments they hold anyway (packed dot products on the VALU).  A wave row's 4 x KSTEPS
+  // fragments per K tile are dealt out to the waves of the first four tile columns that see this A panel (unit = 2 tn + wn),
+  // one fragment each.  Measured alternatives: everything on (tn, wn) = (0, 0) - MFMAs against a ones-column or the same dot
+  // products - makes those workgroups 20-25 % slower and they set the kernel's span; interleaving the dot products with the
+  // MFMAs slows the MFMAs; dealing the K tiles out to ALL tile columns multiplies the atomics on the same addresses.
+  constexpr int CS_ITEMS = 4 * KSTEPS;
+  const int cs_units = min(CS_ITEMS, 2 * g.tiles_n), cs_unit = 2 * tn + wn;
+  unsigned cs_mask = 0;                  // bit w: this wave sums fragment (ks, i) = (w % KSTEPS, w / KSTEPS)
+  if (TA && g.colsum_a != nullptr && cs_unit < cs_units)
+    for (int w = 0; w < CS_ITEMS; ++w) cs_mask |= (w % cs_units == cs_unit) ? (1u << w) : 0u;
+  cs_mask = __builtin_amdgcn_readfirstlane(cs_mask);   // wave-uniform by construction: make the tests scalar branches
+  const bool do_cs = cs_mask != 0;
   float accb[4] = {0.f, 0.f, 0.f, 0.f};   // lane (li, lg): partial sum of row 16 i + li over the k values of lane group lg
 
   const int nk = (kend - kbeg + BK - 1) / BK;
@@ -481,6 +489,16 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
         }
       }
       if (STAGE_LATE && kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
+      if constexpr (TA) {
+        if (do_cs) {
+#pragma unroll
+          for (int w = 0; w < CS_ITEMS; ++w)
+            if ((cs_mask >> w) & 1u) {
+              asm volatile("");   // keeps this a real (scalar) branch: if-converted, every wave would sum all fragments
+              accb[w / KSTEPS] = frag_sum(fa[w % KSTEPS][w / KSTEPS], accb[w / KSTEPS]);
+            }
+        }
+      }
       __builtin_amdgcn_s_setprio(1);
 #pragma unroll
       for (int ks = 0; ks < KSTEPS; ++ks)
@@ -488,14 +506,6 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[ks][i], fb[ks][j], acc[i][j]);
-      if constexpr (TA) {
-        if (do_cs) {
-#pragma unroll
-          for (int ks = 0; ks < KSTEPS; ++ks)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) accb[i] = frag_sum(fa[ks][i], accb[i]);
-        }
-      }
       __builtin_amdgcn_s_setprio(0);
     } else {
 #pragma unroll
@@ -521,7 +531,11 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
       if constexpr (TA) {
         if (do_cs) {
 #pragma unroll
-          for (int i = 0; i < 4; ++i) accb[i] = frag_sum(fa[i], accb[i]);
+          for (int i = 0; i < 4; ++i)
+            if ((cs_mask >> (i * KSTEPS + ks)) & 1u) {
+              asm volatile("");
+              accb[i] = frag_sum(fa[i], accb[i]);
+            }
         }
       }
     }
@@ -529,10 +543,16 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
   }
+  unsigned long long t_pre_cs = 0;
+  if (g.dbg) t_pre_cs = __builtin_amdgcn_s_memrealtime();
   if constexpr (TA) {
     if (do_cs) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
+        bool mine = false;
+#pragma unroll
+        for (int ks = 0; ks < KSTEPS; ++ks) mine |= ((cs_mask >> (i * KSTEPS + ks)) & 1u) != 0;
+        if (!mine) continue;            // wave-uniform
         float v = accb[i];
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
@@ -556,7 +576,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     g.dbg[(size_t)blockIdx.x * 8 + 5] = t_issued;
     unsigned hw = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_ID
     unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
-    d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = __builtin_amdgcn_s_memrealtime(); d[4] = hw;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = __builtin_amdgcn_s_memrealtime(); d[4] = hw; d[6] = t_pre_cs;
   }
 }
 

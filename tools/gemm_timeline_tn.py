@@ -31,5 +31,5 @@ t0 = d[:, 0].min()
 start, loop, loop_end, end = [(d[:, i] - t0) / 100.0 for i in range(4)]
 print(f"blocks {len(d)}; kernel span {end.max():.1f} us")
 for nm, v in (("prologue", loop - start), ("main loop", loop_end - loop), ("epilogue+drain", end - loop_end),
-              ("epilogue issue", (d[:, 5] - t0) / 100.0 - loop_end), ("lifetime", end - start), ("start", start)):
+              ("colsum tail", (d[:, 2] - d[:, 6]) / 100.0), ("epilogue issue", (d[:, 5] - t0) / 100.0 - loop_end), ("lifetime", end - start), ("start", start)):
     print(f"  {nm:16s} median {np.median(v):7.2f}  p90 {np.percentile(v, 90):7.2f}  max {v.max():7.2f}")
