@@ -106,8 +106,10 @@ int missm_mean_rows(const float* in, float* out, int B, int T, int cols, void* s
 int missm_attention_fwd(const void* qkv, void* out, float* lse, int nseq, int L, int H, int head_dim, int ld, int ldo,
                         int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal, const int* key_mask, float scale,
                         int dtype, void* stream);
-int missm_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int nseq, int L, int H, int head_dim,
-                        int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal,
+/* Backward: dqkv[rows, 3*H*hd] from the saved forward tensors.  `out` is the forward output (ld = ldo, like dout): the
+ * softmax-gradient row term D = rowsum(dO . O) is taken from it, so no [L, L] tile is held while a row sum is pending. */
+int missm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int nseq, int L, int H,
+                        int head_dim, int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride, int causal,
                         const int* key_mask, float scale, int dtype, void* stream);
 
 /* Patch unfold: pixels fp32 (frame n = (b, t): base b*stride_b + t*stride_t, channel stride_c, row-major HxW) ->

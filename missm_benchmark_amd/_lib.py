@@ -25,7 +25,7 @@ SIGNATURES = {
     "missm_cast_rows": [P, P, L, I, I, I, I, P],
     "missm_mean_rows": [P, P, I, I, I, P],
     "missm_attention_fwd": [P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, F, I, P],
-    "missm_attention_bwd": [P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, F, I, P],
+    "missm_attention_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, F, I, P],
     "missm_unfold_patches": [P, P, I, I, I, I, I, I, L, L, L, I, P],
     "missm_embed_assemble": [P, P, P, P, I, I, I, I, P],
     "missm_token_embed_fwd": [P, P, P, P, I, I, I, P],
@@ -67,7 +67,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
-    if lib.missm_abi_version() != 1:
+    if lib.missm_abi_version() != 2:
         raise MissmError("libmissm_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib

@@ -163,14 +163,28 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
   }
 }
 
+// dot product of the k values two lanes hold in matching operand fragments (D = rowsum(dO . O))
+__device__ __forceinline__ float frag_dot(bf16x8 x, bf16x8 y, float s) {
+  using bf16x2 = __attribute__((ext_vector_type(2))) __bf16;
+#pragma unroll
+  for (int p = 0; p < 4; ++p) s = __builtin_amdgcn_fdot2_f32_bf16(bf16x2{x[2 * p], x[2 * p + 1]}, bf16x2{y[2 * p], y[2 * p + 1]}, s, false);
+  return s;
+}
+__device__ __forceinline__ float frag_dot(f32x4 x, f32x4 y, float s) { return s + ((x[0] * y[0] + x[1] * y[1]) + (x[2] * y[2] + x[3] * y[3])); }
+
+// Backward.  D[q] = sum_j P[q,j] dP[q,j] is taken from the saved forward output instead (D = dO[q,:] . O[q,:], the same number):
+// the probabilities / score gradients of a tile row can then be packed into MFMA operand fragments as they are produced,
+// two 16-key tiles at a time, instead of living in 2 x NTP fp32 tiles until the row sum is known - 216 -> <= 128 VGPRs at
+// S = 197, i.e. two 8-wave workgroups per CU instead of one.
 template <typename T, int NTP, bool PW>
-__global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) {
+__global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
   constexpr int LP = NTP * 16;
   constexpr int KSQ = HD / M_::KS;
-  constexpr int NU = NTP / M_::CTILES;
+  constexpr int CT = M_::CTILES;
+  constexpr int NU = NTP / CT;
   extern __shared__ __attribute__((aligned(16))) char smem_all[];
   constexpr int SLICE = 2 * LP * RBv + 3 * LP * 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
@@ -189,6 +203,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
   const size_t base = seq_base(a, seq);
   const T* qkv = static_cast<const T*>(a.qkv);
   const T* dout = static_cast<const T*>(a.dout);
+  const T* fout = static_cast<const T*>(a.out);
   T* dqkv = static_cast<T*>(a.dqkv);
   const int L = a.L;
   const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
@@ -198,27 +213,53 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
   for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS) {
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
     lseL[k] = k < L ? lse[k] : __builtin_huge_valf();
-    Dl[k] = 0.f;
   }
   const int nt = (L + 15) / 16;
   constexpr int MAXQ = (NTP + NWV - 1) / NWV;   // query / key tiles per wave
-  Frag qfa[MAXQ][KSQ], dofa[MAXQ][KSQ];
-#pragma unroll
-  for (int t = 0; t < MAXQ; ++t) {
-    const int qi = (wv + t * NWV) * 16 + li;
+  // Q / dO fragments of this wave's FIRST query tile are fetched while the K / V pieces are in flight (the second tile's at
+  // its turn: holding both costs 16 VGPRs the 128-register budget of two workgroups per CU does not have at S = 197);
+  // D of every tile is computed up front, pass B needs all of them.
+  auto load_q = [&](int qt, Frag (&qf)[KSQ], Frag (&dof)[KSQ]) -> float {
+    const int qi = qt * 16 + li;
     const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
+    float dsum = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
-      qfa[t][ks] = M_::zero(); dofa[t][ks] = M_::zero();
+      qf[ks] = M_::zero(); dof[ks] = M_::zero();
       if (qi < L) {
-        qfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
-        dofa[t][ks] = *reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
+        qf[ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+        dof[ks] = *reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
+        const Frag of = *reinterpret_cast<const Frag*>(fout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
+        dsum = frag_dot(dof[ks], of, dsum);
       }
     }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    return dsum;
+  };
+  Frag qf0[KSQ], dof0[KSQ];
+  float dsa[MAXQ];
+  dsa[0] = load_q(wv, qf0, dof0);
+  if (lg == 0) Dl[wv * 16 + li] = dsa[0];
+#pragma unroll
+  for (int t = 1; t < MAXQ; ++t) {          // D of the later tiles only (every query tile belongs to exactly one wave)
+    const int qi = (wv + t * NWV) * 16 + li;
+    const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
+    float dsum = 0.f;
+    if (qi < L) {
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks)
+        dsum = frag_dot(*reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL),
+                        *reinterpret_cast<const Frag*>(fout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL), dsum);
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    dsa[t] = dsum;
+    if (lg == 0 && qi < LP) Dl[qi] = dsum;
   }
   stage_wait<PW>();
 
-  // ---------------- pass A: query on the lane -> dQ, D ----------------
+  // ---------------- pass A: query on the lane -> dQ ----------------
 #pragma unroll
   for (int t = 0; t < MAXQ; ++t) {
     const int qt = wv + t * NWV;
@@ -226,41 +267,40 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
     const int qi = qt * 16 + li;
     const bool qvalid = qi < L;
     const size_t qrow = base + (size_t)(qvalid ? qi : 0) * a.tok_stride;
-    Frag (&qf)[KSQ] = qfa[t];
-    Frag (&dof)[KSQ] = dofa[t];
-    const float lq = lseL[qi];
-    f32x4 p_[NTP], ds[NTP];
-    float dsum = 0.f;
+    Frag qf[KSQ], dof[KSQ];
+    if (t == 0) {
 #pragma unroll
-    for (int kt = 0; kt < NTP; ++kt) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) {
-        const int off = swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
-        s = M_::step(lds_frag<T>(X0, off), qf[ks], s);
-        dp = M_::step(lds_frag<T>(X1, off), dof[ks], dp);
-      }
-      const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * lg + r;
-        float pv = __expf(s[r] * a.scale + kb[r] - lq);
-        if (a.causal && key > qi) pv = 0.f;
-        dsum += pv * dp[r];
-        p_[kt][r] = pv;
-        ds[kt][r] = dp[r];
-      }
+      for (int ks = 0; ks < KSQ; ++ks) { qf[ks] = qf0[ks]; dof[ks] = dof0[ks]; }
+    } else {
+      (void)load_q(qt, qf, dof);
     }
-    dsum += __shfl_xor(dsum, 16, 64);
-    dsum += __shfl_xor(dsum, 32, 64);
-    if (lg == 0) Dl[qi] = qvalid ? dsum : 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NTP; ++kt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) ds[kt][r] = p_[kt][r] * (ds[kt][r] - dsum) * a.scale;
+    const float lq = lseL[qi];
+    const float dsum = dsa[t];
     Frag dsf[NU];
 #pragma unroll
-    for (int u = 0; u < NU; ++u) dsf[u] = M_::from_acc(ds[u * M_::CTILES], ds[u * M_::CTILES + M_::CTILES - 1]);
+    for (int u = 0; u < NU; ++u) {
+      f32x4 dsv[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int kt = u * CT + c;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) {
+          const int off = swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+          sc = M_::step(lds_frag<T>(X0, off), qf[ks], sc);
+          dp = M_::step(lds_frag<T>(X1, off), dof[ks], dp);
+        }
+        const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt * 16 + 4 * lg + r;
+          float pv = __expf(sc[r] * a.scale + kb[r] - lq);
+          if (a.causal && key > qi) pv = 0.f;
+          dsv[c][r] = pv * (dp[r] - dsum) * a.scale;
+        }
+      }
+      dsf[u] = M_::from_acc(dsv[0], dsv[CT - 1]);
+    }
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -275,17 +315,18 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
   // ---------------- pass B: key on the lane -> dK, dV ----------------
   stage_head<T, RBv, NWV>(X0, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, lane, wv);
   stage_head<T, RBv, NWV>(X1, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, lane, wv);
-  Frag kfa[MAXQ][KSQ], vfa[MAXQ][KSQ];
-#pragma unroll
-  for (int t = 0; t < MAXQ; ++t) {
-    const int key = (wv + t * NWV) * 16 + li;
+  // (this wave's K / V fragments are fetched per key tile: prefetching both tiles costs 16 more live VGPRs, which at
+  //  S = 197 is the difference between spilling and not under the 128-VGPR budget of two workgroups per CU)
+  Frag kf0[KSQ], vf0[KSQ];
+  {
+    const int key = wv * 16 + li;
     const size_t krow = base + (size_t)(key < L ? key : 0) * a.tok_stride;
 #pragma unroll
     for (int ks = 0; ks < KSQ; ++ks) {
-      kfa[t][ks] = M_::zero(); vfa[t][ks] = M_::zero();
+      kf0[ks] = M_::zero(); vf0[ks] = M_::zero();
       if (key < L) {
-        kfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
-        vfa[t][ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+        kf0[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+        vf0[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
       }
     }
   }
@@ -297,35 +338,46 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_mfma_kernel(AttnArgs a) 
     const int key = kt * 16 + li;
     const bool kin = key < L;
     const size_t krow = base + (size_t)(kin ? key : 0) * a.tok_stride;
-    Frag (&kf)[KSQ] = kfa[t];
-    Frag (&vf)[KSQ] = vfa[t];
-    const float kb = kbias[key];
-    f32x4 p_[NTP], ds[NTP];
+    Frag kf[KSQ], vf[KSQ];
 #pragma unroll
-    for (int qt = 0; qt < NTP; ++qt) {
-      f32x4 s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks) {
-        const int off = swz<RBv>(qt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
-        s = M_::step(lds_frag<T>(X0, off), kf[ks], s);
-        dp = M_::step(lds_frag<T>(X1, off), vf[ks], dp);
-      }
-      const f32x4 lq = *reinterpret_cast<const f32x4*>(lseL + qt * 16 + 4 * lg);
-      const f32x4 dq = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int q = qt * 16 + 4 * lg + r;
-        float pv = __expf(s[r] * a.scale + kb - lq[r]);
-        if (a.causal && key > q) pv = 0.f;
-        p_[qt][r] = pv;
-        ds[qt][r] = pv * (dp[r] - dq[r]) * a.scale;
+    for (int ks = 0; ks < KSQ; ++ks) {
+      if (t == 0) { kf[ks] = kf0[ks]; vf[ks] = vf0[ks]; }
+      else {
+        kf[ks] = M_::zero(); vf[ks] = M_::zero();
+        if (kin) {
+          kf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+          vf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+        }
       }
     }
+    const float kb = kbias[key];
     Frag pf[NU], dsf[NU];
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      pf[u] = M_::from_acc(p_[u * M_::CTILES], p_[u * M_::CTILES + M_::CTILES - 1]);
-      dsf[u] = M_::from_acc(ds[u * M_::CTILES], ds[u * M_::CTILES + M_::CTILES - 1]);
+      f32x4 pv4[CT], dsv[CT];
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const int qt = u * CT + c;
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) {
+          const int off = swz<RBv>(qt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+          sc = M_::step(lds_frag<T>(X0, off), kf[ks], sc);
+          dp = M_::step(lds_frag<T>(X1, off), vf[ks], dp);
+        }
+        const f32x4 lq = *reinterpret_cast<const f32x4*>(lseL + qt * 16 + 4 * lg);
+        const f32x4 dq = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int q = qt * 16 + 4 * lg + r;
+          float pv = __expf(sc[r] * a.scale + kb - lq[r]);
+          if (a.causal && key > q) pv = 0.f;
+          pv4[c][r] = pv;
+          dsv[c][r] = pv * (dp[r] - dq[r]) * a.scale;
+        }
+      }
+      pf[u] = M_::from_acc(pv4[0], pv4[CT - 1]);
+      dsf[u] = M_::from_acc(dsv[0], dsv[CT - 1]);
     }
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
@@ -595,12 +647,13 @@ extern "C" int missm_attention_fwd(const void* qkv, void* out, float* lse, int n
   return dtype == kBF16 ? launch_attn<bf16, false>(a, head_dim, s) : launch_attn<float, false>(a, head_dim, s);
 }
 
-extern "C" int missm_attention_bwd(const void* qkv, const void* dout, const float* lse, void* dqkv, int nseq, int L, int H,
-                                   int head_dim, int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride,
+extern "C" int missm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, void* dqkv, int nseq, int L,
+                                   int H, int head_dim, int ld, int ldo, int seq_div, int seq_outer, int seq_inner, int tok_stride,
                                    int causal, const int* key_mask, float scale, int dtype, void* stream) {
   MISSM_CHECK_ARG(nseq > 0 && L > 0 && H > 0 && head_dim > 0 && head_dim % 8 == 0 && head_dim <= 128, "attention_bwd: bad shape");
+  MISSM_CHECK_ARG(out != nullptr, "attention_bwd: the forward output is required (D = rowsum(dO . O))");
   MISSM_CHECK_ARG(ld % 8 == 0 && ldo % 8 == 0, "attention_bwd: ld/ldo must be multiples of 8");
-  AttnArgs a; fill_args(a, qkv, nullptr, const_cast<float*>(lse), dout, dqkv, nseq, L, H, head_dim, ld, ldo, seq_div, seq_outer, seq_inner, tok_stride, causal, key_mask, scale);
+  AttnArgs a; fill_args(a, qkv, const_cast<void*>(out), const_cast<float*>(lse), dout, dqkv, nseq, L, H, head_dim, ld, ldo, seq_div, seq_outer, seq_inner, tok_stride, causal, key_mask, scale);
   hipStream_t s = static_cast<hipStream_t>(stream);
   return dtype == kBF16 ? launch_attn<bf16, true>(a, head_dim, s) : launch_attn<float, true>(a, head_dim, s);
 }

@@ -176,14 +176,15 @@ def attention_fwd(qkv, out, lse, nseq, L, H, hd, *, seq_div=1, seq_outer=None, s
     return out
 
 
-def attention_bwd(qkv, dout, lse, dqkv, nseq, L, H, hd, *, seq_div=1, seq_outer=None, seq_inner=0, tok_stride=1, causal=False,
+def attention_bwd(qkv, out, dout, lse, dqkv, nseq, L, H, hd, *, seq_div=1, seq_outer=None, seq_inner=0, tok_stride=1, causal=False,
                   key_mask=None, scale=None):
     seq_outer = L if seq_outer is None else seq_outer
     scale = hd ** -0.5 if scale is None else scale
     rows_needed = ((nseq - 1) // seq_div) * seq_outer + ((nseq - 1) % seq_div) * seq_inner + (L - 1) * tok_stride + 1
-    if min(qkv.shape[0], dout.shape[0], dqkv.shape[0]) < rows_needed or dqkv.stride(0) != qkv.stride(0):
+    if min(qkv.shape[0], dout.shape[0], out.shape[0], dqkv.shape[0]) < rows_needed or dqkv.stride(0) != qkv.stride(0) or \
+            out.stride(0) != dout.stride(0) or out.dtype != qkv.dtype:
         raise _lib.MissmError("attention_bwd: row addressing exceeds the buffers")
-    _lib.call("missm_attention_bwd", qkv.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), nseq, L, H, hd,
+    _lib.call("missm_attention_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), nseq, L, H, hd,
               qkv.stride(0), dout.stride(0), seq_div, seq_outer, seq_inner, tok_stride, int(causal), _p(key_mask), float(scale),
               dt(qkv), _s())
     return dqkv

@@ -462,7 +462,7 @@ class ClipTower(nn.Module):
             dctx = torch.empty(rows, d, device=dev, dtype=T)
             self._linear_bwd(dh_T, ctx, self._w(f"{pfx}.out")[1], L.g_out_w, L.g_out_b, rows, dx_out=dctx)
             dqkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
-            ops.attention_bwd(qkv, dctx, lse, dqkv, N, S, H, hd, causal=s.causal, key_mask=s.key_mask)
+            ops.attention_bwd(qkv, ctx, dctx, lse, dqkv, N, S, H, hd, causal=s.causal, key_mask=s.key_mask)
             dx1 = torch.empty(rows, d, device=dev, dtype=T)
             self._linear_bwd(dqkv, x1, self._w(f"{pfx}.qkv")[1], L.g_qkv_w, L.g_qkv_b, rows, dx_out=dx1)
             ops.layernorm_bwd(dx1, hin, m1, r1, L.ln1_w, dh, L.g_ln1_w, L.g_ln1_b, rows, d, accumulate=True, dx_cast=dh_T)
@@ -471,7 +471,7 @@ class ClipTower(nn.Module):
                 dctx = torch.empty(rows, d, device=dev, dtype=T)
                 self._linear_bwd(dh_T, ctx, self._w(f"{pfx}.tout")[1], L.g_tout_w, L.g_tout_b, rows, dx_out=dctx)
                 dqkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
-                ops.attention_bwd(qkv, dctx, lse, dqkv, B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
+                ops.attention_bwd(qkv, ctx, dctx, lse, dqkv, B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
                 dxt = torch.empty(rows, d, device=dev, dtype=T)
                 self._linear_bwd(dqkv, xt, self._w(f"{pfx}.tqkv")[1], L.g_tqkv_w, L.g_tqkv_b, rows, dx_out=dxt)
                 ops.layernorm_bwd(dxt, hin, mt, rt, L.tln_w, dh, L.g_tln_w, L.g_tln_b, rows, d, accumulate=True, dx_cast=dh_T)

@@ -50,7 +50,7 @@ def test_error_channel_without_gpu(lib):
     rc = lib.missm_gemm_nt(None, None, None, 0, 0, 0, 0, 0, 0, 1.0, None, None, None, None, 0, 0, 0, 0, 1, None)
     assert rc == -1
     assert b"gemm" in lib.missm_last_error()
-    assert lib.missm_abi_version() == 1
+    assert lib.missm_abi_version() == 2
     assert lib.missm_device_count() >= 0
 
 

@@ -279,7 +279,7 @@ def test_attention_fwd_bwd(ops, dtype, case):
     dout = torch.zeros(rows, d)
     dout[rowidx.reshape(-1)] = dout_seq.view(-1, d)
     dqkv = torch.zeros(rows, 3 * d, device="cuda", dtype=dtype)
-    ops.attention_bwd(QKV, dev(dout, dtype), lse, dqkv, nseq, L, H, hd, causal=case["causal"], key_mask=km, **kw)
+    ops.attention_bwd(QKV, out, dev(dout, dtype), lse, dqkv, nseq, L, H, hd, causal=case["causal"], key_mask=km, **kw)
     for i, nm in enumerate("qkv"):
         assert rel(dqkv[:, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d]) < TOL[dtype] * 1.5, nm
 

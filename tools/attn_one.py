@@ -15,13 +15,13 @@ dout = torch.randn(rows, d, device="cuda").to(dt)
 dqkv = torch.empty(rows, 3 * d, device="cuda", dtype=dt)
 for _ in range(3):
     ops.attention_fwd(qkv, out, lse, N, S, H, hd)
-    ops.attention_bwd(qkv, dout, lse, dqkv, N, S, H, hd)
+    ops.attention_bwd(qkv, out, dout, lse, dqkv, N, S, H, hd)
 torch.cuda.synchronize()
 e0, e1, e2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
 e0.record()
 for _ in range(5): ops.attention_fwd(qkv, out, lse, N, S, H, hd)
 e1.record()
-for _ in range(5): ops.attention_bwd(qkv, dout, lse, dqkv, N, S, H, hd)
+for _ in range(5): ops.attention_bwd(qkv, out, dout, lse, dqkv, N, S, H, hd)
 e2.record(); torch.cuda.synchronize()
 fl = 4.0 * S * S * hd * N * H
 print(f"N={N}: fwd {e0.elapsed_time(e1)/5*1e3:.1f} us ({fl/(e0.elapsed_time(e1)/5)/1e9:.1f} TFLOP/s)  bwd {e1.elapsed_time(e2)/5*1e3:.1f} us ({2.5*fl/(e1.elapsed_time(e2)/5)/1e9:.1f} TFLOP/s)")
