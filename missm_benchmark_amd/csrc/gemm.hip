@@ -643,16 +643,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* __restrict__ in, f
   if (cur >= 0) atomicAdd(out + (size_t)cur * C + c, s);
 }
 
-// plain column sum (bias gradients), HBM-bound: 16-byte loads, 8 row-lanes x 32 column-groups per workgroup, each
-// workgroup reduces a 256-row x (32 * VEC)-column panel through LDS and issues one atomic per column.
+// column sum (bias / temporal-embedding gradients), HBM-bound: 16-byte loads, 8 row-lanes x 32 column-groups per workgroup,
+// each workgroup reduces a rpb-row x (32 * VEC)-column panel through LDS and issues one atomic per column.  Grouped form
+// (mod > 1): the rows of one workgroup are one run of `div` rows, all in group (first row / div) % mod -> out[group][c].
 template <typename T>
-__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int C, int ld) {
+__global__ __launch_bounds__(256) void colsum_vec_kernel(const T* __restrict__ in, float* __restrict__ out, int R, int C, int ld,
+                                                        int rpb, int div, int mod) {
   constexpr int VEC = 16 / sizeof(T);
   __shared__ float red[8][32 * VEC + 1];
   const int cg = threadIdx.x & 31, rl = threadIdx.x >> 5;
   const int c0 = (blockIdx.y * 32 + cg) * VEC;
-  const int rbeg = blockIdx.x * 256;
-  const int rend = min(R, rbeg + 256);
+  const int rbeg = blockIdx.x * rpb;
+  const int rend = min(R, rbeg + rpb);
+  out += (size_t)((rbeg / div) % mod) * C;
   float acc[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
@@ -871,10 +874,11 @@ extern "C" int missm_colsum(const void* in, float* out, int R, int C, int ld, in
   MISSM_CHECK_ARG(R > 0 && C > 0 && div > 0 && mod > 0, "colsum: bad shape");
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int vec = dtype == kBF16 ? 8 : 4;
-  if (mod == 1 && C % vec == 0 && ld % vec == 0 && ((uintptr_t)in % 16 == 0)) {
-    dim3 grid((R + 255) / 256, (C + 32 * vec - 1) / (32 * vec)), block(256);
-    if (dtype == kBF16) hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, block, 0, s, (const bf16*)in, out, R, C, ld);
-    else hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, block, 0, s, (const float*)in, out, R, C, ld);
+  if ((mod == 1 || div >= 32) && C % vec == 0 && ld % vec == 0 && ((uintptr_t)in % 16 == 0)) {
+    const int rpb_v = mod == 1 ? 256 : div;        // grouped: one run of `div` rows (one group) per workgroup
+    dim3 grid((R + rpb_v - 1) / rpb_v, (C + 32 * vec - 1) / (32 * vec)), block(256);
+    if (dtype == kBF16) hipLaunchKernelGGL(colsum_vec_kernel<bf16>, grid, block, 0, s, (const bf16*)in, out, R, C, ld, rpb_v, mod == 1 ? 1 : div, mod);
+    else hipLaunchKernelGGL(colsum_vec_kernel<float>, grid, block, 0, s, (const float*)in, out, R, C, ld, rpb_v, mod == 1 ? 1 : div, mod);
     return missm_check_launch("colsum_vec");
   }
   int rpb = 128;

@@ -155,6 +155,11 @@ def test_colsum_groups_and_cast(ops, dtype):
     out = torch.zeros(d, device="cuda")
     ops.colsum(dev(x, dtype), out)
     assert rel(out, x.sum(0)) < 1e-5
+    B2, T2, S2, d2 = 2, 3, 37, 136            # runs of >= 32 rows take the vectorised grouped kernel (ragged column panel)
+    x2 = q(rnd(B2 * T2 * S2, d2, seed=4), dtype)
+    out = torch.zeros(T2, d2, device="cuda")
+    ops.colsum(dev(x2, dtype), out, div=S2, mod=T2)
+    assert rel(out, x2.view(B2, T2, S2, d2).sum((0, 2))) < 1e-5
     w = rnd(100, 72, seed=2)
     wd = torch.empty(100, 72, device="cuda", dtype=dtype)
     wt = torch.empty(72, 100, device="cuda", dtype=dtype)
