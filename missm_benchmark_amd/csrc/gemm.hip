@@ -40,6 +40,7 @@ struct GemmArgs {
   float* ws;                // split-K workspace: [splitk][tiles][16][256] float4 partial accumulators (register order)
   unsigned long long* dbg;  // diagnostic builds only: per-workgroup {start, loop start, loop end, end, hw id} stamps (100 MHz clock)
   int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
+  int exp_flags;            // TEMPORARY timing experiments (wrong results): 1 = no staging in the loop
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
 };
 
@@ -232,7 +233,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
 template <typename T> struct AuxPre { static constexpr bool ok = false; using V = int; };
 template <> struct AuxPre<bf16> { static constexpr bool ok = true; using V = bf16x4; };
 
-template <typename T, bool TB>
+template <typename T, bool TB, bool GENERIC_OK = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4][4], int mw, int nw, int split, int lane,
                                               f32x4 bias4, float* wave_lds, const typename AuxPre<T>::V (&upre)[4][4],
                                               bool have_upre) {
@@ -317,7 +318,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
       const float* R = g.resid;
       MISSM_EPI_LOOP(if (R) { const f32x4 q = load4(R + off); v += q; } store4(C + off, v);)
     } else {                                                            // ragged edges, rare activations, accumulate
-      epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds);
+      if constexpr (GENERIC_OK) epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds);
+      else __builtin_trap();                                            // host dispatch never sends these to the big tile
     }
 #undef MISSM_EPI_LOOP
   }
@@ -331,8 +333,16 @@ template <int RBK> __device__ __forceinline__ int kswz(int row, int chunk) {
   else return row * 64 + ((chunk ^ ((0x78 >> (((row >> 2) & 3) << 1)) & 3)) << 4);   // g = [0,2,3,1]: conflict-free b128 reads
 }
 
-template <typename T, bool TA, bool TB, int RBK, int VAR = 0>
-__global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(GemmArgs g) {
+// WG = waves per side of the workgroup's wave grid: 2 -> 128x128 tile, 256 threads, two workgroups per CU;
+//                                                    4 -> 256x256 tile, 1024 threads, one workgroup per CU (NT form only).
+// The per-wave code is the same (64x64 accumulators); the big tile halves the L2 -> LDS bytes staged per flop, which is what
+// bounds the small tile on long-M shapes (the main loop runs 31 % faster with staging switched off; 512 workgroups x 32 KiB
+// per K tile is ~19 TB/s of L2 traffic).  It needs full 64-column wave blocks and a vector epilogue (no LDS-backed generic
+// path: 16 waves x 16 KiB would not fit), which the host dispatch guarantees.
+template <typename T, bool TA, bool TB, int RBK, int VAR = 0, int WG = 2>
+__global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) void gemm_kernel(GemmArgs g) {
+  static_assert(WG == 2 || (WG == 4 && !TA && !TB), "the 256x256 tile exists for the NT form only");
+  constexpr int BMt = 64 * WG, BNt = 64 * WG, NWAVES = WG * WG;
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
@@ -340,17 +350,17 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   constexpr int KSTEPS = BK / M_::KS;     // 2 or 1
   constexpr int RBT = KMajorFrag<T, 128>::RBT; // bytes per row of a k-major tile (128 elements)
   constexpr int NCT = RBT / 16;           // 16-byte chunks per k-major row
-  constexpr int TILE_BYTES = BM * RBK;    // 16 or 8 KiB, either layout
+  constexpr int TILE_BYTES = BMt * RBK;   // 16 or 8 KiB (32 KiB for the 256-row tile), either layout
   constexpr int NCK = RBK / 16;           // chunks per k-contiguous row
-  constexpr int PPW = TILE_BYTES / 4096;  // 1-KiB pieces per wave per operand tile (4 or 2)
+  constexpr int PPW = TILE_BYTES / (NWAVES * 1024);  // 1-KiB pieces per wave per operand tile (4 or 2)
   constexpr int RPK = 1024 / RBK;         // k-contiguous rows per piece
-  __shared__ __attribute__((aligned(16))) char lds[4 * TILE_BYTES];
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // 4 * TILE_BYTES
   char* ldsA = lds;                       // [2][TILE_BYTES]
   char* ldsB = lds + 2 * TILE_BYTES;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WG, wn = wave % WG;
 
   const int ntiles = g.tiles_m * g.tiles_n;
   const int bid = blockIdx.x;
@@ -358,7 +368,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   const int logical = xcd_remap(bid - split * ntiles, ntiles);
   int tm, tn;
   tile_of(logical, g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMt, n0 = tn * BNt;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
 
@@ -390,7 +400,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     if constexpr (!TB) {
       const int lr = RPK * pi + lane / NCK, c = (kswz<RBK>(lr, lane % NCK) - lr * RBK) >> 4;
       // LDS row lr holds tile row r (output column n0 + r) with lr = 64*(r/64) + 16*(r%4) + (r%64)/4
-      const int r = (lr & 64) + ((lr & 15) << 2) + ((lr >> 4) & 3);
+      const int r = (lr & ~63) + ((lr & 15) << 2) + ((lr >> 4) & 3);
       int gn = n0 + r; gn = gn < g.N ? gn : g.N - 1;
       b_src[i] = B + (size_t)gn * g.ldb + c * EPC;
       b_ok[i] = true; b_kofs[i] = c * EPC;
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
   const f32x4 bias4 = prefetch_bias(g, n0 + wn * 64, 0, lane);
   typename AuxPre<T>::V upre[4][4];
   bool have_upre = false;
-  if constexpr (AuxPre<T>::ok && !TB) {
+  if constexpr (AuxPre<T>::ok && !TB && WG == 2) {
     const int nw_ = n0 + wn * 64;
     have_upre = g.act == MISSM_ACT_DQGELU && !g.out_f32 && g.vec_ok && !g.accumulate && nw_ + 64 <= g.N && g.splitk == 1;
     if (have_upre) {
@@ -469,7 +479,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
     // the fragment reads: the compiler cannot see that ds_read_b64_tr_b16 (an intrinsic without memory operands) does not
     // alias the DMA's LDS writes and would put s_waitcnt vmcnt(0) - the whole global-load latency - in front of the reads.
     constexpr bool STAGE_LATE = VAR == 2 && (TA || TB);
-    if (!STAGE_LATE && kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
+    if (!STAGE_LATE && kt + 1 < nk && !(g.exp_flags & 1)) stage(buf ^ 1, kbeg + (kt + 1) * BK);
     const char* la = ldsA + buf * TILE_BYTES;
     const char* lb = ldsB + buf * TILE_BYTES;
     if constexpr (VAR == 2) {
@@ -568,7 +578,7 @@ __global__ __launch_bounds__(GEMM_THREADS, RBK == 128 ? 2 : 4) void gemm_kernel(
 #pragma unroll
     for (int v = 0; v < 16; ++v) mine[v * 256] = acc[v >> 2][v & 3];
   } else {
-    gemm_epilogue<T, TB>(g, acc, m0 + wm * 64, n0 + wn * 64, 0, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384), upre, have_upre);
+    gemm_epilogue<T, TB, WG == 2>(g, acc, m0 + wm * 64, n0 + wn * 64, 0, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384), upre, have_upre);
   }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
@@ -789,6 +799,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   static const int group_m_env = getenv("MISSM_GEMM_GROUP_M") ? atoi(getenv("MISSM_GEMM_GROUP_M")) : 0;
   g.group_m = 1;   // set once the tile grid is known
   g.dbg = missm_gemm_debug_buffer;
+  static const int exp_env = getenv("MISSM_GEMM_EXP") ? atoi(getenv("MISSM_GEMM_EXP")) : 0;
+  g.exp_flags = exp_env;
   static const int variant = getenv("MISSM_GEMM_VARIANT") ? atoi(getenv("MISSM_GEMM_VARIANT")) : -1;   // scheduling experiments
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
@@ -823,15 +835,38 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
+  // ---- 256x256 tile (16 waves, one workgroup per CU) for long-M NT products whose tile grid fills whole rounds of 256 CUs
+  static const int big_env = getenv("MISSM_GEMM_BIG") ? atoi(getenv("MISSM_GEMM_BIG")) : -1;   // 0 never, 1 whenever legal
+  if (dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && big_env != 0 &&
+      (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU)) {
+    const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2;
+    const int rounds = (t2 + 255) / 256;
+    const bool fills = t2 >= 512 && t2 * 100 >= rounds * 256 * 75;       // >= 75 % of the last-round-padded grid is real work
+    if (big_env == 1 || fills) {
+      g.tiles_m = tm2; g.tiles_n = tn2;
+      g.group_m = group_m_env > 0 ? group_m_env : (tn2 >= 4 ? 8 : 1);
+      auto k = gemm_kernel<bf16, false, false, 128, 1, 4>;
+      static bool attr_set = false;
+      if (!attr_set) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+          missm_set_error("gemm: cannot raise dynamic LDS to 128 KiB");
+          return MISSM_ERR_LAUNCH;
+        }
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(k, dim3(t2), dim3(1024), 128 * 1024, s, g);
+      return missm_check_launch("gemm256");
+    }
+  }
   // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
   const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 2 : (K > 1024 ? 2 : 1));
 #define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
   do {                                                                                                     \
-    if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 0, s, g);          \
-    else if (var == 2) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 2>), grid, block, 0, s, g);          \
-    else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 0, s, g);                           \
+    if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 64 * 1024, s, g);  \
+    else if (var == 2) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 2>), grid, block, 64 * 1024, s, g);  \
+    else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 64 * 1024, s, g);                   \
   } while (0)
   if (dtype == kBF16) {
     if (!trans_a && !trans_b) MISSM_GEMM_LAUNCH(bf16, false, false);

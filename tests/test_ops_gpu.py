@@ -124,6 +124,37 @@ def test_gemm_layouts_and_splitk(ops, dtype, M, N, K):
     assert rel(o32, a @ b.t() + bias) < TOL[dtype]
 
 
+def test_gemm_256_tile(ops):
+    """long-M bf16 NT products whose 256x256 tile grid fills whole rounds of the chip take the 16-wave kernel: ragged M,
+    a ragged 64-column tail in N, and each of its epilogues (bias, quick_gelu + saved pre-activation, its derivative,
+    fp32 output + residual) against the fp32 reference; also that it agrees with the 128x128 kernel where both apply."""
+    dtype = torch.bfloat16
+    M, N, K = 8192 - 40, 4096 - 64, 192          # 32 x 16 = 512 tiles of 256x256
+    a, b, bias = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2, scale=0.1), dtype), rnd(N, seed=3)
+    A, Bm = dev(a, dtype), dev(b, dtype)
+    pre = a @ b.t() + bias
+    out = torch.empty(M, N, device="cuda", dtype=dtype)
+    aux = torch.empty(M, N, device="cuda", dtype=dtype)
+    ops.gemm_nt(A, Bm, out, bias=dev(bias))
+    assert rel(out, pre) < TOL[dtype]
+    ops.gemm_nt(A, Bm, out, bias=dev(bias), act=ops.ACT_QGELU, aux_out=aux)
+    assert rel(aux, pre) < TOL[dtype] and rel(out, pre * torch.sigmoid(1.702 * pre)) < TOL[dtype]
+    u = q(rnd(M, N, seed=5), dtype)
+    ur = u.clone().requires_grad_(True)
+    (ur * torch.sigmoid(1.702 * ur)).sum().backward()
+    ops.gemm_nt(A, Bm, out, act=ops.ACT_DQGELU, aux_in=dev(u, dtype))
+    assert rel(out, (a @ b.t()) * ur.grad) < TOL[dtype]
+    res = rnd(M, N, seed=6)
+    o32 = dev(res.clone())
+    ops.gemm_nt(A, Bm, o32, bias=dev(bias), resid=o32)
+    assert rel(o32, res + pre) < TOL[dtype]
+    # the same product through the 128x128 kernel (a sub-block: 128 tiles do not fill the big grid's rounds)
+    sub = torch.empty(2048, N, device="cuda", dtype=dtype)
+    ops.gemm_nt(A[:2048], Bm, sub, bias=dev(bias))
+    ops.gemm_nt(A, Bm, out, bias=dev(bias))
+    assert torch.equal(sub, out[:2048])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_gemm_zero_padded_k(ops, dtype):
     """weight-gradient form: both operands are transposed copies zero-padded along K"""
