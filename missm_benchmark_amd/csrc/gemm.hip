@@ -843,7 +843,24 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
     const int rounds = (t2 + 255) / 256;
     const bool fills = t2 >= 512 && t2 * 100 >= rounds * 256 * 75;       // >= 75 % of the last-round-padded grid is real work
     if (big_env == 1 || fills) {
-      g.tiles_m = tm2; g.tiles_n = tn2;
+      // A last round that would be mostly idle goes to the 128x128 kernel instead: the big tiles take the tile rows that fill
+      // whole rounds of 256 CUs, the remaining rows are a second, small launch (e.g. N = 768: 591 big tiles = 2.3 rounds ->
+      // 510 big tiles + 324 small ones).
+      const int full = t2 / 256, rem = t2 - full * 256;
+      int m_big = M;
+      if (big_env != 1 && full >= 2 && rem > 0 && rem < 160) m_big = (full * 256 / tn2) * 256;
+      if (m_big < M) {
+        const size_t esz = 2, csz = out_f32 ? 4 : 2;
+        int rc = missm_gemm(static_cast<const char*>(A) + (size_t)m_big * lda * esz, B, static_cast<char*>(C) + (size_t)m_big * ldc * csz,
+                            M - m_big, N, K, lda, ldb, ldc, 0, 0, alpha, bias, resid ? resid + (size_t)m_big * ldc : nullptr,
+                            aux_in ? static_cast<const char*>(aux_in) + (size_t)m_big * ldaux * esz : nullptr,
+                            aux_out ? static_cast<char*>(aux_out) + (size_t)m_big * ldaux * esz : nullptr, ldaux, act, out_f32,
+                            accumulate, 1, nullptr, dtype, stream);
+        if (rc) return rc;
+        g.M = m_big;
+      }
+      const int tmb = (g.M + 255) / 256;
+      g.tiles_m = tmb; g.tiles_n = tn2;
       g.group_m = group_m_env > 0 ? group_m_env : (tn2 >= 4 ? 8 : 1);
       auto k = gemm_kernel<bf16, false, false, 128, 1, 4>;
       static bool attr_set = false;
@@ -854,7 +871,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
         }
         attr_set = true;
       }
-      hipLaunchKernelGGL(k, dim3(t2), dim3(1024), 128 * 1024, s, g);
+      hipLaunchKernelGGL(k, dim3(tmb * tn2), dim3(1024), 128 * 1024, s, g);
       return missm_check_launch("gemm256");
     }
   }

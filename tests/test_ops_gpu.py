@@ -153,6 +153,14 @@ def test_gemm_256_tile(ops):
     ops.gemm_nt(A[:2048], Bm, sub, bias=dev(bias))
     ops.gemm_nt(A, Bm, out, bias=dev(bias))
     assert torch.equal(sub, out[:2048])
+    # N = 768: 570 big tiles = 2 full rounds of 256 CUs + 58 -> the rows of the mostly idle last round go to the 128x128 kernel
+    M, N, K = 190 * 256 - 24, 768, 64
+    a, b, bias = q(rnd(M, K, seed=11), dtype), q(rnd(N, K, seed=12, scale=0.1), dtype), rnd(N, seed=13)
+    res = rnd(M, N, seed=16)
+    o32 = dev(res.clone())
+    ops.gemm_nt(dev(a, dtype), dev(b, dtype), o32, bias=dev(bias), resid=o32)
+    assert rel(o32, res + a @ b.t() + bias) < TOL[dtype]
+    assert rel(o32[-3000:], (res + a @ b.t() + bias)[-3000:]) < TOL[dtype]
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
