@@ -69,9 +69,10 @@ class FlatStore:
         return self.grad
 
     def zero_accumulated(self):
-        """clear the gradient buffer: biases / LayerNorm / embedding gradients are accumulated with atomics, and so are
-        the split-K partial products of the weight gradients"""
-        self.ensure_grad().zero_()
+        """clear the part of the gradient buffer that is accumulated into (biases / LayerNorm / embedding gradients: atomics).
+        The GEMM weight blocks in front of it are overwritten by every backward (split-K slices meet in a workspace, the
+        reduce kernel stores), so the ~340 MB of them per tower are not cleared."""
+        self.ensure_grad()[self.vec_start:].zero_()
 
     def move(self, fn):
         new = fn(self.master)

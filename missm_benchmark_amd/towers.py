@@ -412,8 +412,9 @@ class ClipTower(nn.Module):
 
     # ------------------------------------------------------------------ backward implementation
     def _linear_bwd(self, dy, x, wt, g_w, g_b, rows, dx_out=None, act=ops.ACT_NONE, aux_in=None):
-        """dW = dy^T x: TN GEMM reading dy / x where they lie, split-K partials added atomically into the zeroed fp32
-        gradient; db = colsum(dy); dx = dy W through the transposed compute-dtype shadow (NT form, vector epilogue)."""
+        """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result
+        STORED into the fp32 gradient); db += colsum(dy) riding in the same GEMM (zeroed tail of the gradient buffer);
+        dx = dy W through the transposed compute-dtype shadow (NT form, vector epilogue)."""
         ops.gemm(dy, x, g_w, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_b)
         if dx_out is not None:
             ops.gemm(dy, wt, dx_out, act=act, aux_in=aux_in, M=rows)
