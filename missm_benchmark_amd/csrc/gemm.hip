@@ -51,6 +51,24 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];   // source of
 __device__ __forceinline__ int tkey(int row) { return (row & 3) | (((row >> 3) & 1) << 2); }
 template <int RBT> __device__ __forceinline__ int tswz(int row, int chunk16) { return row * RBT + ((chunk16 ^ (tkey(row) << 1)) << 4); }
 
+// The same read issued through inline assembly: the compiler then neither knows it is an LDS read (it would otherwise put
+// s_waitcnt vmcnt(0) in front of it whenever an LDS-DMA is in flight - it cannot prove the intrinsic does not alias the DMA's
+// LDS writes) nor waits for its result: frag_fence() must stand between these reads and their first use.
+__device__ __forceinline__ bf16x8 kmajor_load_untracked(const char* a0, const char* a1) {
+  i16x4 lo, hi;
+  const unsigned p0 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)a0;
+  const unsigned p1 = (unsigned)(size_t)(const __attribute__((address_space(3))) char*)a1;
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(p0));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(hi) : "v"(p1));
+  using i16x8 = __attribute__((ext_vector_type(8))) short;
+  i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+template <typename F> __device__ __forceinline__ void frag_fence(F (&a)[4], F (&b)[4]) {
+  asm volatile("s_waitcnt lgkmcnt(0)"
+               : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]), "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]));
+}
+
 // fragment (one MFMA step) of a k-major tile [BK rows of k][COLS columns]: lane (i, g) gets column c0 + i, its KPL k values
 template <typename T, int COLS> struct KMajorFrag;
 template <int COLS> struct KMajorFrag<bf16, COLS> {
@@ -66,9 +84,16 @@ template <int COLS> struct KMajorFrag<bf16, COLS> {
     i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
     return __builtin_bit_cast(bf16x8, v);
   }
+  static constexpr bool has_untracked = true;
+  __device__ static __forceinline__ bf16x8 load_untracked(const char* lds, int ks, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+    const int r1 = ks * 32 + 8 * g + q, col = c0 + 4 * p;
+    return kmajor_load_untracked(lds + tswz<RBT>(r1, col >> 3) + ((col & 7) << 1), lds + tswz<RBT>(r1 + 4, col >> 3) + ((col & 7) << 1));
+  }
 };
 template <int COLS> struct KMajorFrag<float, COLS> {
   static constexpr int RBT = COLS * 4;
+  static constexpr bool has_untracked = false;
   __device__ static __forceinline__ f32x4 load(const char* lds, int ks, int c0, int lane) {
     const int i = lane & 15, g = lane >> 4, col = c0 + i;
     f32x4 v;
@@ -76,6 +101,7 @@ template <int COLS> struct KMajorFrag<float, COLS> {
     for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const float*>(lds + tswz<RBT>(ks * 16 + 4 * g + j, col >> 2) + ((col & 3) << 2));
     return v;
   }
+  __device__ static __forceinline__ f32x4 load_untracked(const char* lds, int ks, int c0, int lane) { return load(lds, ks, c0, lane); }
 };
 
 // sum of the k values one lane holds in an operand fragment (bias gradient riding in the dW GEMM): packed bf16 dot
@@ -177,19 +203,20 @@ __device__ __forceinline__ void epilogue_generic(const GemmArgs& g, f32x4 (&acc)
 // its accumulators in the per-stream workspace in REGISTER order - thread t, vector v -> float4 #(v*256 + t): coalesced, and
 // identical in every slice - and a second, chip-wide kernel sums the slices in slice order (bit-reproducible) and applies
 // alpha / bias / accumulate.  One workgroup per (tile, i): thread t owns the same (row, col) set the GEMM thread t owned.
-template <bool TB>
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(GemmArgs g) {
+template <bool TB, int WG>
+__global__ __launch_bounds__(64 * WG * WG) void splitk_reduce_kernel(GemmArgs g) {
+  constexpr int NWAVES = WG * WG, NT = 64 * NWAVES;
   const int ntiles = g.tiles_m * g.tiles_n;
   const int tile = blockIdx.x >> 2, i = blockIdx.x & 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, li = lane & 15, lg = lane >> 4;
   int tm, tn;
   tile_of(xcd_remap(tile, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-  const int mw = tm * BM + (wave >> 1) * 64, nw = tn * BN + (wave & 1) * 64;
-  const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + (size_t)tile * 4096 + (i * 4) * 256 + tid;
+  const int mw = tm * (64 * WG) + (wave / WG) * 64, nw = tn * (64 * WG) + (wave % WG) * 64;
+  const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + (size_t)tile * (NWAVES * 1024) + (i * 4) * NT + tid;
   f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int sl = 0; sl < g.splitk; ++sl, p += (size_t)ntiles * 4096) {
+  for (int sl = 0; sl < g.splitk; ++sl, p += (size_t)ntiles * (NWAVES * 1024)) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) a[j] += __builtin_nontemporal_load(p + j * 256);
+    for (int j = 0; j < 4; ++j) a[j] += __builtin_nontemporal_load(p + j * NT);
   }
   float* C = static_cast<float*>(g.C);
 #pragma unroll
@@ -243,7 +270,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, f32x4 (&acc)[4]
     // (register arrays must only ever be indexed with compile-time constants: a rolled loop here sends `acc` to scratch)
     const bool plain_f = g.out_f32 && g.act == MISSM_ACT_NONE && !g.resid && !g.accumulate;   // weight gradients
     const bool plain_t = !g.out_f32 && g.act == MISSM_ACT_NONE;
-    if (!plain_f && !plain_t) { epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds); return; }
+    if (!plain_f && !plain_t) {
+      if constexpr (GENERIC_OK) epilogue_generic<T, TB>(g, acc, mw, nw, split, lane, wave_lds);
+      else __builtin_trap();
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int col = nw + j * 16 + li;
@@ -341,14 +372,14 @@ template <int RBK> __device__ __forceinline__ int kswz(int row, int chunk) {
 // path: 16 waves x 16 KiB would not fit), which the host dispatch guarantees.
 template <typename T, bool TA, bool TB, int RBK, int VAR = 0, int WG = 2>
 __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) void gemm_kernel(GemmArgs g) {
-  static_assert(WG == 2 || (WG == 4 && !TA && !TB), "the 256x256 tile exists for the NT form only");
+  static_assert(WG == 2 || (WG == 4 && !TA && !TB), "the 256x256 tile is instantiated for the NT form only");
   constexpr int BMt = 64 * WG, BNt = 64 * WG, NWAVES = WG * WG;
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int EPC = 16 / sizeof(T);     // elements per 16-byte chunk
   constexpr int BK = RBK / sizeof(T);     // k elements per tile (64 or 32 bf16 / 32 or 16 f32)
   constexpr int KSTEPS = BK / M_::KS;     // 2 or 1
-  constexpr int RBT = KMajorFrag<T, 128>::RBT; // bytes per row of a k-major tile (128 elements)
+  constexpr int RBT = KMajorFrag<T, BMt>::RBT; // bytes per row of a k-major tile (128 elements)
   constexpr int NCT = RBT / 16;           // 16-byte chunks per k-major row
   constexpr int TILE_BYTES = BMt * RBK;   // 16 or 8 KiB (32 KiB for the 256-row tile), either layout
   constexpr int NCK = RBK / 16;           // chunks per k-contiguous row
@@ -439,7 +470,7 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
   // products - makes those workgroups 20-25 % slower and they set the kernel's span; interleaving the dot products with the
   // MFMAs slows the MFMAs; dealing the K tiles out to ALL tile columns multiplies the atomics on the same addresses.
   constexpr int CS_ITEMS = 4 * KSTEPS;
-  const int cs_units = min(CS_ITEMS, 2 * g.tiles_n), cs_unit = 2 * tn + wn;
+  const int cs_units = min(CS_ITEMS, WG * g.tiles_n), cs_unit = WG * tn + wn;
   unsigned cs_mask = 0;                  // bit w: this wave sums fragment (ks, i) = (w % KSTEPS, w / KSTEPS)
   if (TA && g.colsum_a != nullptr && cs_unit < cs_units)
     for (int w = 0; w < CS_ITEMS; ++w) cs_mask |= (w % cs_units == cs_unit) ? (1u << w) : 0u;
@@ -490,12 +521,12 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           if constexpr (!TA) fa[ks][i] = lds_frag<T>(la, kswz<RBK>(wm * 64 + i * 16 + li, ks * 4 + lg));
-          else fa[ks][i] = KMajorFrag<T, 128>::load(la, ks, wm * 64 + i * 16, lane);
+          else fa[ks][i] = KMajorFrag<T, BMt>::load(la, ks, wm * 64 + i * 16, lane);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           if constexpr (!TB) fb[ks][j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, ks * 4 + lg));
-          else fb[ks][j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
+          else fb[ks][j] = KMajorFrag<T, BMt>::load(lb, ks, wn * 64 + j * 16, lane);
         }
       }
       if (STAGE_LATE && kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
@@ -525,19 +556,16 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         if constexpr (!TA) fa[i] = lds_frag<T>(la, kswz<RBK>(wm * 64 + i * 16 + li, cchunk));
-        else fa[i] = KMajorFrag<T, 128>::load(la, ks, wm * 64 + i * 16, lane);
+        else fa[i] = KMajorFrag<T, BMt>::load_untracked(la, ks, wm * 64 + i * 16, lane);
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if constexpr (!TB) fb[j] = lds_frag<T>(lb, kswz<RBK>(wn * 64 + j * 16 + li, cchunk));
-        else fb[j] = KMajorFrag<T, 128>::load(lb, ks, wn * 64 + j * 16, lane);
+        else fb[j] = KMajorFrag<T, BMt>::load_untracked(lb, ks, wn * 64 + j * 16, lane);
       }
-      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
-      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
+      // k-major fragments came through untracked inline-assembly reads (no s_waitcnt vmcnt(0) in front of them while the
+      // next tile's LDS-DMA is in flight): this is the wait for them
+      if constexpr ((TA || TB) && KMajorFrag<T, BMt>::has_untracked) frag_fence(fa, fb);
       if constexpr (TA) {
         if (do_cs) {
 #pragma unroll
@@ -548,6 +576,12 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
             }
         }
       }
+      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = M_::step(fa[i], fb[j], acc[i][j]);
+      if constexpr (VAR == 1) __builtin_amdgcn_s_setprio(0);
     }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -574,9 +608,9 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
 
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
   if (g.splitk > 1) {   // K slice: park the partial tile for splitk_reduce_kernel
-    f32x4* mine = reinterpret_cast<f32x4*>(g.ws) + ((size_t)split * ntiles + (bid - split * ntiles)) * 4096 + tid;
+    f32x4* mine = reinterpret_cast<f32x4*>(g.ws) + ((size_t)split * ntiles + (bid - split * ntiles)) * (NWAVES * 1024) + tid;
 #pragma unroll
-    for (int v = 0; v < 16; ++v) mine[v * 256] = acc[v >> 2][v & 3];
+    for (int v = 0; v < 16; ++v) mine[v * (64 * NWAVES)] = acc[v >> 2][v & 3];
   } else {
     gemm_epilogue<T, TB, WG == 2>(g, acc, m0 + wm * 64, n0 + wn * 64, 0, lane, bias4, reinterpret_cast<float*>(lds + wave * 16384), upre, have_upre);
   }
@@ -597,7 +631,11 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
 //   * 128x128 / K tile 32 / 4-stage ring, two workgroups per CU                 : 768 at 4096^3, 615-650 on the video shapes;
 //   * the same ring kept running across output tiles (persistent workgroups)    : 665 at 4096^3 (the counted vmcnt then also
 //     waits for the previous tile's epilogue stores);
-//   * staggering co-resident workgroups by 6-25 us                               : -2..-5 %.
+//   * staggering co-resident workgroups by 6-25 us                               : -2..-5 %;
+//   * the 256x256 / 16-wave tile for the weight-gradient (TN) form, split-K over one round of 256 workgroups: 575-647 TFLOP/s
+//     on the video dW shapes against 643-690 for the 128x128 kernel (its 128-VGPR budget has no room to preload both K steps'
+//     fragments, so the k-major reads go through untracked inline-assembly loads behind an early LDS-DMA - load_untracked,
+//     frag_fence, which the 128x128 kernel's VARIANT 1 still uses - and the 62 MB of partial tiles cost 20 us to reduce).
 // What did pay: global_load_lds staging, s_setprio around the MFMA cluster (+4-10 % at K = 768), requesting all fragments
 // of a K tile up front (+10 % at long K), a compact epilogue (instruction cache; +16 % at K = 768), bias prefetch, split-K
 // sized to ONE resident wave of workgroups, grouped tile order.  This kernel: 1088 TFLOP/s at 4096^3, 740-830 on the video
@@ -808,6 +846,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   // measured on the video tower (GROUP_M 1 / 8 / 16): QKV 668 / 732 / 756, fc1 646 / 692 / 703, fc2 (6 tile columns) 795 / 772 / 729
   g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 12 ? 16 : (g.tiles_n >= 8 ? 8 : 1));
   const int bk = dtype == kBF16 ? 64 : 32;
+  static const int big_env = getenv("MISSM_GEMM_BIG") ? atoi(getenv("MISSM_GEMM_BIG")) : -1;   // 0 never, 1 whenever legal
   const int tiles = g.tiles_m * g.tiles_n;
   const int fill = 512;   // workgroups that fill the chip once (2 per CU)
   if (splitk <= 0) {  // auto: fill the chip exactly ONCE (2 workgroups x 256 CUs) - one resident wave of blocks, no tail.
@@ -836,7 +875,6 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   hipStream_t s = static_cast<hipStream_t>(stream);
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // ---- 256x256 tile (16 waves, one workgroup per CU) for long-M NT products whose tile grid fills whole rounds of 256 CUs
-  static const int big_env = getenv("MISSM_GEMM_BIG") ? atoi(getenv("MISSM_GEMM_BIG")) : -1;   // 0 never, 1 whenever legal
   if (dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && big_env != 0 &&
       (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU)) {
     const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2;
@@ -896,8 +934,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   }
 #undef MISSM_GEMM_LAUNCH
   if (splitk > 1) {
-    if (trans_b) hipLaunchKernelGGL(splitk_reduce_kernel<true>, dim3(tiles * 4), block, 0, s, g);
-    else hipLaunchKernelGGL(splitk_reduce_kernel<false>, dim3(tiles * 4), block, 0, s, g);
+    if (trans_b) hipLaunchKernelGGL((splitk_reduce_kernel<true, 2>), dim3(tiles * 4), block, 0, s, g);
+    else hipLaunchKernelGGL((splitk_reduce_kernel<false, 2>), dim3(tiles * 4), block, 0, s, g);
   }
   return missm_check_launch("gemm");
 }
