@@ -129,15 +129,19 @@ int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* 
 /* eot[b] = argmax_s ids[b, s] (first occurrence), image/modeling_image.py:519-522. */
 int missm_argmax_rows(const long* ids, int* out, int B, int S, void* stream);
 
-/* y[b, o] = sum_i x[b, i] w[o, i] (+ bias[o]) -> optional ReLU ; all fp32 (projection / fusion tail).
- * row_code/code: rows with row_code[b] == code produce 0 (modality missing, src/model/baseline.py:57);
+/* y[b, o] = sum_i x[b, i] w[o, i] (+ bias[o]) -> optional ReLU ; all fp32 (projection / fusion tail).  y has row stride
+ * ldy >= O, so a head can write its slice of a concatenated feature row (torch.cat, src/model/baseline.py:84,176).
+ * row_code/code: rows with row_code[b] == code produce 0 (modality missing, src/model/baseline.py:57) - or, when x_sub[I]
+ * is given, are computed from that row instead of x[b] (zero / mean / median imputation, src/model/baseline.py:80-82);
  * accumulate: y += (sum over modalities). */
-int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
-                           const long* row_code, long code, int accumulate, void* stream);
-/* dx[b,i] (= or +=), dw[o,i] (=), dbias[o] (=) for the layer above; dy is masked by row_code/code and, when
- * relu_y is given, by relu_y > 0. */
-int missm_small_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw, float* dbias,
-                           int B, int I, int O, const long* row_code, long code, int accumulate_dx, void* stream);
+int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int ldy, int relu,
+                           const long* row_code, long code, const float* x_sub, int accumulate, void* stream);
+/* dx[b,i] (= or +=), dw[o,i] (=), dbias[o] (=) for the layer above; dy (row stride lddy) is masked by row_code/code and,
+ * when relu_y is given, by relu_y > 0.  With x_sub the masked rows still feed dw / dbias (their input was x_sub); only
+ * their dx is zero. */
+int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
+                           float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
+                           int accumulate_dx, void* stream);
 /* y = x / ||x||_2 * scale   (languagebind/__init__.py:80-83) and its backward. */
 int missm_l2norm_scale_fwd(const float* x, float* y, int B, int D, float scale, void* stream);
 int missm_l2norm_scale_bwd(const float* dy, const float* x, float* dx, int B, int D, float scale, void* stream);

@@ -91,15 +91,16 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
 // ---- small fp32 linears of the projection / fusion tail: one wavefront per output element ----
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int I, int O,
-                                                              int relu, const long* __restrict__ row_code, long code, int accumulate) {
+                                                              int ldy, int relu, const long* __restrict__ row_code, long code,
+                                                              const float* __restrict__ x_sub, int accumulate) {
   const int lane = threadIdx.x & 63;
   const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= (long)B * O) return;
   const int b = e / O, o = e % O;
   float acc = 0.f;
   const bool masked = row_code && row_code[b] == code;
-  if (!masked) {
-    const float* xr = x + (long)b * I;
+  if (!masked || x_sub) {       // a masked row is either zeroed or computed from the substitute input row
+    const float* xr = masked ? x_sub : x + (long)b * I;
     const float* wr = w + (long)o * I;
     for (int i = lane * 4; i < I; i += 256) {
       const f32x4 a = load4(xr + i), c = load4(wr + i);
@@ -109,13 +110,13 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __re
     if (bias) acc += bias[o];
     if (relu) acc = fmaxf(acc, 0.f);
   }
-  if (lane == 0) y[e] = accumulate ? y[e] + acc : acc;
+  if (lane == 0) { float* yp = y + (long)b * ldy + o; *yp = accumulate ? *yp + acc : acc; }
 }
 
 // effective dy (masked by row code and by relu) helper
-__device__ __forceinline__ float eff_dy(const float* dy, const float* relu_y, const long* row_code, long code, int b, int o, int O) {
+__device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* relu_y, const long* row_code, long code, int b, int o, int O) {
   if (row_code && row_code[b] == code) return 0.f;
-  const float g = dy[(long)b * O + o];
+  const float g = dy[(long)b * lddy + o];
   if (relu_y && relu_y[(long)b * O + o] <= 0.f) return 0.f;
   return g;
 }
@@ -124,28 +125,30 @@ __device__ __forceinline__ float eff_dy(const float* dy, const float* relu_y, co
 // partial sums added atomically into a zeroed / accumulated dx) so the launch fills the chip instead of 96 workgroups
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
-                                                             const long* __restrict__ row_code, long code, int accumulate) {
+                                                             int lddy, const long* __restrict__ row_code, long code, int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * I) return;
   const int b = idx / I, i = idx % I;
   const int o0 = blockIdx.y * 32, o1 = min(O, o0 + 32);
   float acc = 0.f;
-  for (int o = o0; o < o1; ++o) acc += eff_dy(dy, relu_y, row_code, code, b, o, O) * w[(long)o * I + i];
+  for (int o = o0; o < o1; ++o) acc += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O) * w[(long)o * I + i];
   atomicAdd(dx + idx, acc);
 }
 
 // dw[o, i] = sum_b dyeff[b, o] x[b, i] ; dbias[o] = sum_b dyeff[b, o]
 __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ relu_y, float* __restrict__ dw,
-                                                             float* __restrict__ dbias, int B, int I, int O,
-                                                             const long* __restrict__ row_code, long code) {
+                                                             float* __restrict__ dbias, int B, int I, int O, int lddy,
+                                                             const long* __restrict__ row_code, long code, const float* __restrict__ x_sub) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)O * I) return;
   const int o = idx / I, i = idx % I;
   float acc = 0.f, accb = 0.f;
   for (int b = 0; b < B; ++b) {
-    const float g = eff_dy(dy, relu_y, row_code, code, b, o, O);
-    acc += g * x[(long)b * I + i];
+    // with a substitute row the masked samples still feed the weights (their input is x_sub), only dx is cut
+    const bool subst = x_sub && row_code && row_code[b] == code;
+    const float g = eff_dy(dy, lddy, relu_y, subst ? nullptr : row_code, code, b, o, O);
+    acc += g * (subst ? x_sub[i] : x[(long)b * I + i]);
     accb += g;
   }
   dw[idx] = acc;
@@ -307,23 +310,25 @@ extern "C" int missm_argmax_rows(const long* ids, int* out, int B, int S, void* 
   return missm_check_launch("argmax_rows");
 }
 
-extern "C" int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int relu,
-                                      const long* row_code, long code, int accumulate, void* stream) {
-  MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && I % 4 == 0, "small_linear_fwd: bad shape (I must be a multiple of 4)");
+extern "C" int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int ldy, int relu,
+                                      const long* row_code, long code, const float* x_sub, int accumulate, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && I % 4 == 0 && ldy >= O, "small_linear_fwd: bad shape (I must be a multiple of 4, ldy >= O)");
+  MISSM_CHECK_ARG(!x_sub || row_code, "small_linear_fwd: a substitute row needs row codes");
   const long e = (long)B * O;
-  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, relu, row_code, code, accumulate);
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, ldy, relu, row_code, code, x_sub, accumulate);
   return missm_check_launch("small_linear_fwd");
 }
 
-extern "C" int missm_small_linear_bwd(const float* dy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
-                                      float* dbias, int B, int I, int O, const long* row_code, long code, int accumulate_dx,
-                                      void* stream) {
-  MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0, "small_linear_bwd: bad shape");
+extern "C" int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
+                                      float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
+                                      int accumulate_dx, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && lddy >= O, "small_linear_bwd: bad shape");
+  MISSM_CHECK_ARG(!relu_y || lddy == O, "small_linear_bwd: the relu mask is dense, dy must be too");
   if (dx) {
     if (!accumulate_dx) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * I, S_(stream)) != hipSuccess) { missm_set_error("small_linear_bwd: memset failed"); return MISSM_ERR_LAUNCH; } }
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, row_code, code, accumulate_dx);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, accumulate_dx);
   }
-  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, row_code, code);
+  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub);
   return missm_check_launch("small_linear_bwd");
 }
 

@@ -100,6 +100,51 @@ def fused_modal_sum(missing_index: torch.Tensor, codes: Sequence[int], xs, linea
                               *[l.bias for l in linears])
 
 
+class _ConcatLinearFn(torch.autograd.Function):
+    """z = cat_m(x_m W_m^T + b_m) along the feature axis, each projection writing its own column slice of z (no torch.cat);
+    rows whose missing code matches modality m take the substitute input row sub_m instead of x_m (the reference overwrites
+    the embedding rows with the zero / mean / median statistics buffer, src/model/baseline.py:80-82), so they still feed
+    dW / db but pass no gradient back to the encoder."""
+
+    @staticmethod
+    def forward(ctx, missing, codes, n, *tensors):
+        xs, ws, bs, subs = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n], tensors[3 * n:]
+        _gpu(xs[0], "fusion projection")
+        xs = tuple(x.contiguous().float() for x in xs)
+        F = ws[0].shape[0]
+        z = torch.empty(xs[0].shape[0], n * F, device=xs[0].device, dtype=torch.float32)
+        for i in range(n):
+            ops.small_linear_fwd(xs[i], ws[i], bs[i], z[:, i * F:(i + 1) * F], row_code=missing if subs[i] is not None else None,
+                                 code=codes[i], x_sub=subs[i])
+        ctx.save_for_backward(missing, *xs, *ws, *[s if s is not None else xs[0].new_empty(0) for s in subs])
+        ctx.codes, ctx.n, ctx.has_sub = codes, n, tuple(s is not None for s in subs)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        n = ctx.n
+        missing = ctx.saved_tensors[0]
+        xs, ws, subs = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:1 + 2 * n], ctx.saved_tensors[1 + 2 * n:]
+        dz = dz.contiguous()
+        F = ws[0].shape[0]
+        dxs, dws, dbs = [], [], []
+        for i in range(n):
+            dx, dw = torch.empty_like(xs[i]), torch.empty_like(ws[i])
+            db = torch.empty(F, device=dz.device, dtype=torch.float32)
+            ops.small_linear_bwd(dz[:, i * F:(i + 1) * F], xs[i], ws[i], dx, dw, db, row_code=missing if ctx.has_sub[i] else None,
+                                 code=ctx.codes[i], x_sub=subs[i] if ctx.has_sub[i] else None)
+            dxs.append(dx); dws.append(dw); dbs.append(db)
+        return (None, None, None, *dxs, *dws, *dbs, *([None] * n))
+
+
+def fused_modal_concat(missing_index, codes: Sequence[int], xs, linears: Sequence[HipLinear], substitutes=None):
+    """substitutes: per modality a [feature_dims] fp32 row (imputation statistics) or None (no masking at all)."""
+    n = len(xs)
+    subs = list(substitutes) if substitutes is not None else [None] * n
+    return _ConcatLinearFn.apply(missing_index.contiguous(), tuple(int(c) for c in codes), n, *xs, *[l.weight for l in linears],
+                                 *[l.bias for l in linears], *subs)
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

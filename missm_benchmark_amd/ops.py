@@ -226,19 +226,24 @@ def argmax_rows(ids, out, B, S):
     return out
 
 
-def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, accumulate=False):
+def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, x_sub=None, accumulate=False):
+    """y may be a column slice of a wider row-major buffer (its row stride is passed on)."""
     B, I = x.shape
     O = w.shape[0]
-    _lib.call("missm_small_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, I, O, int(relu), _p(row_code),
-              int(code), int(accumulate), _s())
+    if y.shape[0] < B or y.shape[1] != O or y.stride(1) != 1 or not x.is_contiguous() or not w.is_contiguous():
+        raise _lib.MissmError("small_linear_fwd: bad operand layout")
+    _lib.call("missm_small_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, I, O, y.stride(0), int(relu),
+              _p(row_code), int(code), _p(x_sub), int(accumulate), _s())
     return y
 
 
-def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, accumulate_dx=False):
+def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, x_sub=None, accumulate_dx=False):
     B, I = x.shape
     O = w.shape[0]
-    _lib.call("missm_small_linear_bwd", dy.data_ptr(), x.data_ptr(), w.data_ptr(), _p(relu_y), _p(dx), _p(dw), _p(dbias), B, I, O,
-              _p(row_code), int(code), int(accumulate_dx), _s())
+    if dy.shape[1] != O or dy.stride(1) != 1:
+        raise _lib.MissmError("small_linear_bwd: bad dy layout")
+    _lib.call("missm_small_linear_bwd", dy.data_ptr(), dy.stride(0), x.data_ptr(), w.data_ptr(), _p(relu_y), _p(dx), _p(dw), _p(dbias),
+              B, I, O, _p(row_code), int(code), _p(x_sub), int(accumulate_dx), _s())
 
 
 def l2norm_scale_fwd(x, y, scale):

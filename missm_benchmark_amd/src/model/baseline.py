@@ -2,7 +2,8 @@
 
 ``finetune_model(args, output_dims, encoder_model)`` keeps the reference constructor / attributes / forward:
 ``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
-fusion_dim, dropout_prob, fusion_type``.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90) and ``'retrieval'``
+(:164-180) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
 the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
 state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
 
@@ -63,7 +64,41 @@ class modal_sum(_FusionBase):
         return self.head(self.norm(z))
 
 
-_NOT_YET = ("concat", "regression", "retrieval", "intra_attention", "inter_attention", "graph_fusion", "unified_graph",
+class modal_concat(_FusionBase):
+    """Zero / mean / median composition (reference :64-90): a missing modality's embedding rows are replaced by the
+    ``statistics_<modal>`` buffer (zeros until ``set_statistics``), every modality is projected and the projections are
+    concatenated."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim * len(args.modality_types))
+        for m in self.modality_types:
+            self.register_buffer(f"statistics_{m}", torch.zeros(args.feature_dims, dtype=torch.float))
+
+    def forward(self, batch, missing_index):
+        return self.head(self.norm(hnn.fused_modal_concat(
+            missing_index, self._codes(), [batch[m] for m in self.modality_types], [self.modal_proj[m] for m in self.modality_types],
+            [self.get_buffer(f"statistics_{m}") for m in self.modality_types])))
+
+    def set_statistics(self, statistics, modality_types):
+        """reference :88-90 (called from test.py:115 with per-modality mean / median embeddings of the training set)"""
+        for m in modality_types:
+            dev = self.modal_proj[m].weight.device
+            self.register_buffer(f"statistics_{m}", torch.as_tensor(statistics[m], dtype=torch.float, device=dev).contiguous())
+
+
+class modal_concat_full(_FusionBase):
+    """Retrieval-based composition (reference :164-180): missing embeddings were already filled upstream by retrieval, so
+    the head is projection + concatenation with no masking."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim * len(args.modality_types))
+
+    def forward(self, batch, missing_index):
+        return self.head(self.norm(hnn.fused_modal_concat(
+            missing_index, self._codes(), [batch[m] for m in self.modality_types], [self.modal_proj[m] for m in self.modality_types])))
+
+
+_NOT_YET = ("regression", "intra_attention", "inter_attention", "graph_fusion", "unified_graph",
             "dedicated_dnn", "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
 
 
@@ -74,6 +109,10 @@ class finetune_model(nn.Module):
         self.fusion_type = args.fusion_type
         if args.fusion_type == "sum":
             self.fusion = modal_sum(args, output_dims)
+        elif args.fusion_type == "concat":
+            self.fusion = modal_concat(args, output_dims)
+        elif args.fusion_type == "retrieval":
+            self.fusion = modal_concat_full(args, output_dims)
         elif args.fusion_type in _NOT_YET:
             raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
         else:

@@ -128,34 +128,42 @@ def text_fixture(name, cfg: O.TextCfg, batch, seed_w, seed_x, grad_names=()):
           f"{float((p - pooled).abs().max()):.2e}; ref-encoder-vs-oracle pooled {float((p - pr).abs().max()):.2e}")
 
 
-def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classes, seed):
+def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classes, seed, fusion_type="sum"):
     base = ref_shims.ref_baseline()
     args = types.SimpleNamespace(modality_types=list(modality_types), feature_dims=feature_dims, fusion_dim=fusion_dim,
-                                 dropout_prob=0.0, fusion_type="sum")
+                                 dropout_prob=0.0, fusion_type=fusion_type)
 
     class _Enc(torch.nn.Module):  # stands in for LanguageBind: returns the embeddings it is given
         def forward(self, data):
             return data
 
     model = base.finetune_model(args, classes, _Enc()).eval()
-    fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed)
-    model.fusion.load_state_dict(fp)
+    head_in = fusion_dim if fusion_type == "sum" else fusion_dim * len(modality_types)
+    fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed, head_in=head_in)
+    model.fusion.load_state_dict(fp, strict=False)        # (the concat head also carries statistics_<modal> buffers)
     g = _gen(seed + 1)
+    stats = None
+    if fusion_type == "concat":                            # test.py:112-115: mean / median embeddings of the training set
+        stats = {m: torch.randn(feature_dims, generator=g) * 0.5 for m in modality_types}
+        model.fusion.set_statistics({m: s.tolist() for m, s in stats.items()}, modality_types)
     emb = {m: torch.randn(batch, feature_dims, generator=g, requires_grad=True) for m in modality_types}
     codes = [0] + [base.missing_type_index[m] for m in modality_types]
     missing = torch.tensor([codes[i % len(codes)] for i in range(batch)], dtype=torch.int64)
     labels = torch.randint(0, classes, (batch,), generator=g)
-    logits = model({m: e for m, e in emb.items()}, missing)
+    # (non-leaf copies, as encoder outputs are: modal_concat overwrites the missing rows of its inputs in place, :82)
+    logits = model({m: e * 1.0 for m, e in emb.items()}, missing)
     loss = torch.nn.CrossEntropyLoss()(logits, labels)
     loss.backward()
     fix = {"modality_types": list(modality_types), "params": fp, "emb": {m: e.detach() for m, e in emb.items()},
            "missing_index": missing, "labels": labels, "logits": logits.detach(), "loss": loss.detach(),
            "emb_grads": {m: e.grad.clone() for m, e in emb.items()},
            "grads": {k: v.grad.clone() for k, v in model.fusion.named_parameters()},
-           "missing_type_index": dict(base.missing_type_index)}
+           "missing_type_index": dict(base.missing_type_index), "fusion_type": fusion_type, "statistics": stats}
     torch.save(fix, os.path.join(OUT, name + ".pt"))
     with torch.no_grad():
-        lo = O.fusion_sum({m: e.detach() for m, e in emb.items()}, missing, fp, modality_types)
+        e0 = {m: e.detach() for m, e in emb.items()}
+        lo = O.fusion_sum(e0, missing, fp, modality_types) if fusion_type == "sum" else \
+            O.fusion_concat(e0, missing, fp, modality_types, stats, mask=fusion_type == "concat")
     print(f"{name}: ref-vs-oracle logits {float((lo - logits).abs().max()):.2e}")
 
 
@@ -210,6 +218,12 @@ def missing_fixture(name):
 
 
 def main():
+    only = set(sys.argv[1:])        # optional: names of the fixtures to (re)generate; default all
+
+    def run(fn, name, *a, **k):
+        if not only or name in only:
+            fn(name, *a, **k)
+
     tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16)
     lname = "encoder.layers.0"
     vis_grads = ("embeddings.class_embedding", "embeddings.patch_embedding.weight", "embeddings.position_embedding.weight",
@@ -217,25 +231,29 @@ def main():
                  f"{lname}.self_attn.v_proj.weight", f"{lname}.self_attn.out_proj.weight", f"{lname}.layer_norm1.weight",
                  f"{lname}.layer_norm2.bias", f"{lname}.mlp.fc1.weight", f"{lname}.mlp.fc1.bias", f"{lname}.mlp.fc2.weight",
                  "encoder.layers.1.mlp.fc2.bias", "post_layernorm.weight", "post_layernorm.bias")
-    vision_fixture("vision_tiny", "image", O.VisionCfg(**tiny), batch=3, seed_w=0, seed_x=1, grad_names=vis_grads)
+    run(vision_fixture, "vision_tiny", "image", O.VisionCfg(**tiny), batch=3, seed_w=0, seed_x=1, grad_names=vis_grads)
     vid_grads = vis_grads + (f"{lname}.temporal_embedding", f"{lname}.temporal_attn.q_proj.weight",
                              f"{lname}.temporal_attn.out_proj.bias", f"{lname}.temporal_layer_norm1.weight")
-    vision_fixture("video_tiny", "video", O.VisionCfg(**tiny, add_time_attn=True, num_frames=4), batch=2, seed_w=3, seed_x=4,
+    run(vision_fixture, "video_tiny", "video", O.VisionCfg(**tiny, add_time_attn=True, num_frames=4), batch=2, seed_w=3, seed_x=4,
                    grad_names=vid_grads)
     # a 197-token, head_dim-64 case small enough to commit: exercises the production attention shape
-    vision_fixture("vision_s197", "image",
+    run(vision_fixture, "vision_s197", "image",
                    O.VisionCfg(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,
                                image_size=224, patch_size=16), batch=2, seed_w=5, seed_x=6, store_params=False,
                    grad_names=(f"{lname}.self_attn.q_proj.weight", f"{lname}.mlp.fc1.bias"), compact=True)
-    text_fixture("text_tiny", O.TextCfg(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
+    run(text_fixture, "text_tiny", O.TextCfg(vocab_size=512, hidden_size=64, intermediate_size=128, num_hidden_layers=2,
                                         num_attention_heads=2, max_position_embeddings=16), batch=5, seed_w=7, seed_x=8,
                  grad_names=("embeddings.token_embedding.weight", "embeddings.position_embedding.weight",
                              f"{lname}.self_attn.q_proj.weight", f"{lname}.mlp.fc2.weight", "final_layer_norm.weight"))
-    fusion_fixture("fusion_sum", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5, seed=11)
-    bundle_fixture("bundle", seed=12)
-    missing_fixture("missing_index")
+    run(fusion_fixture, "fusion_sum", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5, seed=11)
+    run(fusion_fixture, "fusion_concat", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5, seed=21,
+                   fusion_type="concat")
+    run(fusion_fixture, "fusion_retrieval", ["language", "video", "image"], batch=9, feature_dims=48, fusion_dim=32, classes=4, seed=22,
+                   fusion_type="retrieval")
+    run(bundle_fixture, "bundle", seed=12)
+    run(missing_fixture, "missing_index")
     # BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224 (weights by recipe, outputs stored)
-    vision_fixture("vitb16_config1", "image", O.VisionCfg(), batch=4, seed_w=0, seed_x=1, store_params=False, compact=True)
+    run(vision_fixture, "vitb16_config1", "image", O.VisionCfg(), batch=4, seed_w=0, seed_x=1, store_params=False, compact=True)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))
 

@@ -292,6 +292,24 @@ def fusion_sum(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modali
     return head_forward(z, fp)
 
 
+def fusion_concat(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                  statistics: Optional[Dict[str, Tensor]] = None, mask: bool = True,
+                  codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_concat.forward`` src/model/baseline.py:77-86 (mask=True: rows of a missing modality are overwritten with its
+    ``statistics_<modal>`` buffer - zeros unless ``set_statistics`` ran, :74-75,88-90 - BEFORE the projection) and
+    ``modal_concat_full.forward`` :172-180 (mask=False); projections concatenated, LayerNorm, Head."""
+    parts = []
+    for m in modality_types:
+        x = emb[m]
+        if mask:
+            st = statistics[m] if statistics is not None else torch.zeros(x.shape[-1])
+            x = torch.where((missing_index == codes[m])[:, None], st[None].to(x.dtype), x)
+        parts.append(F.linear(x, fp[f"modal_proj.{m}.weight"], fp[f"modal_proj.{m}.bias"]))
+    z = torch.cat(parts, dim=-1)
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
@@ -389,16 +407,18 @@ def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
 
 
 def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
-                       seed: int) -> Params:
-    """Seeded init for ``modal_sum`` + ``Head`` (src/model/baseline.py:27-50) parameter names."""
+                       seed: int, head_in: Optional[int] = None) -> Params:
+    """Seeded init for ``modal_sum`` / ``modal_concat`` / ``modal_concat_full`` + ``Head`` (src/model/baseline.py:27-50,66-71)
+    parameter names; head_in = width of the fused row (fusion_dim for sum, fusion_dim * M for the concat heads)."""
     gen = torch.Generator().manual_seed(seed)
+    head_in = fusion_dim if head_in is None else head_in
     fp: Params = {}
     for m in modality_types:
         fp[f"modal_proj.{m}.weight"] = _normal((fusion_dim, feature_dims), feature_dims ** -0.5, gen)
         fp[f"modal_proj.{m}.bias"] = _normal((fusion_dim,), 0.02, gen)
-    fp["norm.weight"] = 1.0 + _normal((fusion_dim,), 0.02, gen)
-    fp["norm.bias"] = _normal((fusion_dim,), 0.02, gen)
-    fp["head.head.0.weight"] = _normal((fusion_dim, fusion_dim), fusion_dim ** -0.5, gen)
+    fp["norm.weight"] = 1.0 + _normal((head_in,), 0.02, gen)
+    fp["norm.bias"] = _normal((head_in,), 0.02, gen)
+    fp["head.head.0.weight"] = _normal((fusion_dim, head_in), head_in ** -0.5, gen)
     fp["head.head.0.bias"] = _normal((fusion_dim,), 0.02, gen)
     fp["head.head.3.weight"] = _normal((num_classes, fusion_dim), fusion_dim ** -0.5, gen)
     fp["head.head.3.bias"] = _normal((num_classes,), 0.02, gen)

@@ -387,6 +387,18 @@ def test_small_linear_l2norm_ce_dropout(ops):
     dx, dw, db = torch.empty(B, I, device="cuda"), torch.empty(O, I, device="cuda"), torch.empty(O, device="cuda")
     ops.small_linear_bwd(dev(dy), dev(x), dev(w), dx, dw, db, row_code=dev(code), code=2)
     assert rel(dx, xr.grad) < 1e-5 and rel(dw, wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    # column slice of a wider row (concat heads) + substitute input row for the masked samples (imputation)
+    sub_row = rnd(I, seed=6)
+    wide = torch.full((B, 3 * O), 9.0, device="cuda")
+    ops.small_linear_fwd(dev(x), dev(w), dev(b), wide[:, O:2 * O], row_code=dev(code), code=2, x_sub=dev(sub_row))
+    xr.grad = wr.grad = br.grad = None
+    xin = torch.where((code == 2)[:, None], sub_row[None], xr)
+    refs = F.linear(xin, wr, br)
+    assert rel(wide[:, O:2 * O], refs) < 1e-5 and float(wide[:, :O].min()) == 9.0 and float(wide[:, 2 * O:].min()) == 9.0
+    dwide = rnd(B, 3 * O, seed=7)
+    refs.backward(dwide[:, O:2 * O])
+    ops.small_linear_bwd(dev(dwide)[:, O:2 * O], dev(x), dev(w), dx, dw, db, row_code=dev(code), code=2, x_sub=dev(sub_row))
+    assert rel(dx, xr.grad) < 1e-5 and rel(dw, wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
     # relu variant
     yr = torch.empty(B, O, device="cuda")
     ops.small_linear_fwd(dev(x), dev(w), dev(b), yr, relu=True)

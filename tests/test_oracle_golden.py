@@ -1,6 +1,7 @@
 """Pin the CPU oracle against fixtures produced by RUNNING the reference (oracle/make_golden.py).
 
 CPU-only; these are the `-m "not gpu"` checks that the oracle restates the reference."""
+import pytest
 import torch
 
 import missm_oracle as O
@@ -101,6 +102,23 @@ def test_fusion_sum_and_loss():
     fp = {k: v.clone().requires_grad_(True) for k, v in fix["params"].items()}
     emb = {m: e.clone().requires_grad_(True) for m, e in fix["emb"].items()}
     logits = O.fusion_sum(emb, fix["missing_index"], fp, fix["modality_types"])
+    assert (logits - fix["logits"]).abs().max() < TOL
+    loss = O.cross_entropy(logits, fix["labels"])
+    assert abs(float(loss.detach()) - float(fix["loss"])) < TOL
+    loss.backward()
+    for m in emb:
+        assert (emb[m].grad - fix["emb_grads"][m]).abs().max() < TOL
+    for k, g in fix["grads"].items():
+        assert (fp[k].grad - g).abs().max() < TOL, k
+
+
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval"])
+def test_fusion_concat_heads(name):
+    """modal_concat (imputation statistics set through set_statistics) and modal_concat_full against the reference's outputs"""
+    fix = load_golden(name)
+    fp = {k: v.clone().requires_grad_(True) for k, v in fix["params"].items()}
+    emb = {m: e.clone().requires_grad_(True) for m, e in fix["emb"].items()}
+    logits = O.fusion_concat(emb, fix["missing_index"], fp, fix["modality_types"], fix["statistics"], mask=fix["fusion_type"] == "concat")
     assert (logits - fix["logits"]).abs().max() < TOL
     loss = O.cross_entropy(logits, fix["labels"])
     assert abs(float(loss.detach()) - float(fix["loss"])) < TOL

@@ -172,6 +172,37 @@ def test_fusion_sum_and_bundle_vs_reference_fixture(pkg, dtype, tol):
         assert rel(hnn.l2norm_scale(e, scale), ref) < 1e-5
 
 
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval"])
+def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
+    """fusion_type 'concat' (zero / mean / median imputation through set_statistics, test.py:112-115) and 'retrieval':
+    projections written straight into their slice of the concatenated row; logits, loss and every gradient against the
+    fixture captured from the reference."""
+    fix = load_golden(name)
+    mt = fix["modality_types"]
+    fd = fix["params"]["modal_proj." + mt[0] + ".weight"].shape
+    args = types.SimpleNamespace(modality_types=mt, feature_dims=fd[1], fusion_dim=fd[0], dropout_prob=0.0, fusion_type=fix["fusion_type"])
+    C = fix["logits"].shape[1]
+    model = pkg.base.finetune_model(args, C, torch.nn.Identity())
+    assert type(model.fusion).__name__ == {"concat": "modal_concat", "retrieval": "modal_concat_full"}[fix["fusion_type"]]
+    missing, unexpected = model.fusion.load_state_dict(fix["params"], strict=False)
+    assert not unexpected and all(k.startswith("statistics_") for k in missing)
+    model = model.cuda()
+    if fix["statistics"] is not None:
+        model.fusion.set_statistics({m: s.tolist() for m, s in fix["statistics"].items()}, mt)
+        assert all(f"statistics_{m}" in model.fusion.state_dict() for m in mt)
+    emb = {m: e.cuda().requires_grad_(True) for m, e in fix["emb"].items()}
+    logits = model(emb, fix["missing_index"].cuda())
+    assert rel(logits, fix["logits"]) < 1e-5
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    loss = HipCrossEntropyLoss()(logits, fix["labels"].cuda())
+    assert abs(float(loss) - float(fix["loss"])) < 1e-5
+    loss.backward()
+    for m in mt:
+        assert rel(emb[m].grad, fix["emb_grads"][m]) < 1e-4, m
+    for k, g in fix["grads"].items():
+        assert rel(model.fusion.get_parameter(k).grad, g) < 1e-4, k
+
+
 def _tiny_model(pkg, dtype, seed=0):
     T = pkg.towers.TowerConfig
     tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16)
