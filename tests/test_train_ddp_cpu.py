@@ -57,3 +57,14 @@ def test_gather_and_reduce_world2():
     for _, g, r in res:
         assert g == [[0.0] * 3] * 2 + [[1.0] * 3] * 2 and r == 1.5
     assert T.gather_tensor(torch.ones(2), 1).tolist() == [1.0, 1.0]
+
+
+def test_test_py_cli_and_statistics():
+    from missm_benchmark_amd import test as TT
+    a = TT.parse_args([])
+    # reference test.py:15-40
+    assert (a.datasetName, a.model_ckpt_dir, a.fusion_dim, a.batch_size, a.seed) == ("eNTERFACE", "./final_model", 256, 64, 42)
+    assert a.modality_types == ["video", "audio"] and a.test_missing_type == ["video", "audio", "mixed"]
+    assert TT.parse_args(["--test_types", "concat_zero,concat_mean"]).test_types == ["concat_zero", "concat_mean"]
+    chunks = [np.array([[1.0, 2.0], [3.0, 10.0]]), np.array([[5.0, 0.0]])]
+    assert TT.calculate_statistics(chunks, "mean") == [3.0, 4.0] and TT.calculate_statistics(chunks, "median") == [3.0, 2.0]

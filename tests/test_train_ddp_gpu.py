@@ -62,6 +62,39 @@ def test_no_grad_forward_equals_training_forward(pkg):
     assert not b.requires_grad and torch.equal(a.detach(), b)
 
 
+def test_missing_ratio_sweep_with_mean_imputation(pkg, tmp_path, monkeypatch):
+    """test.py drop-in: checkpoint written in train_ddp's final-model layout, 'concat' head, concat_mean statistics taken from
+    the encoder over the training batches (checked against the CPU oracle's embeddings), one result file per scenario."""
+    from missm_benchmark_amd import test as TT
+    monkeypatch.chdir(tmp_path)
+    model, cfgs, tcfg, margs = _tiny_model(pkg, torch.float32)
+    args = TT.parse_args(["--modality_types", "language,video,image", "--feature_dims", "48", "--fusion_dim", "32", "--dropout_prob", "0.0",
+                          "--fusion_type", "concat", "--test_types", "concat_zero,concat_mean", "--test_missing_type", "video,mixed",
+                          "--datasetName", "synthetic"])
+    ref = pkg.base.finetune_model(args, 5, model.encoder)
+    os.makedirs("final_model")
+    torch.save({"model_state_dict": ref.state_dict()}, "final_model/synthetic_concat.pth")
+    tp, tc, proj, scales, _ = _oracle_of(model, cfgs, tcfg, margs)
+    train = _batches(3, 6, 40, missing=False)
+    loaders = {"video": {0.0: _batches(2, 6, 50, missing=False), 0.5: _batches(2, 6, 60)}, "mixed": {0.3: _batches(2, 6, 70)}}
+    out, metrics = TT.test(args, train, loaders, 5, encoder_model=model.encoder, compute_dtype=torch.float32, log=lambda s: None)
+    assert set(metrics) == {"loss", "accuracy", "f1", "auc"}
+    for nm in ("synthetic_concat_zero_video", "synthetic_concat_zero_mixed", "synthetic_concat_mean_video", "synthetic_concat_mean_mixed"):
+        txt = (tmp_path / "new_txt_experiment" / f"{nm}.txt").read_text()
+        assert txt.count("Testing with missing ratio") == (2 if nm.endswith("video") else 1) and "Test AUC" in txt
+    embs = {m: [] for m in args.modality_types}
+    with torch.no_grad():
+        for data, _, miss in train:
+            d = {m: {k: v.squeeze(1) for k, v in x.items()} for m, x in data.items()}
+            _, e = O.finetune_forward(d, miss, tp, tc, proj, scales, {k[len("fusion."):]: v for k, v in model.state_dict().items()
+                                                                      if k.startswith("fusion.")}, margs.modality_types)
+            for m in embs:
+                embs[m].append(e[m].numpy())
+    for m in args.modality_types:
+        want = torch.tensor(np.concatenate(embs[m]).mean(0))
+        assert rel(out.fusion.get_buffer(f"statistics_{m}"), want) < 1e-3, m
+
+
 def test_train_loop_checkpoints_and_learns(pkg, tmp_path, monkeypatch):
     from missm_benchmark_amd import train_ddp as T
     monkeypatch.chdir(tmp_path)
