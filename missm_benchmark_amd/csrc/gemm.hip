@@ -632,6 +632,8 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
 //   * the same ring kept running across output tiles (persistent workgroups)    : 665 at 4096^3 (the counted vmcnt then also
 //     waits for the previous tile's epilogue stores);
 //   * staggering co-resident workgroups by 6-25 us                               : -2..-5 %;
+//   * a 256x256 tile as 8 waves of 128x64 with a 32-deep K tile (64 KiB of LDS, two workgroups per CU, 198 VGPRs): 755-810
+//     TFLOP/s on the video NT shapes against 843-1006 for the 16-wave version below (twice the barriers per MFMA);
 //   * the 256x256 / 16-wave tile for the weight-gradient (TN) form, split-K over one round of 256 workgroups: 575-647 TFLOP/s
 //     on the video dW shapes against 643-690 for the 128x128 kernel (its 128-VGPR budget has no room to preload both K steps'
 //     fragments, so the k-major reads go through untracked inline-assembly loads behind an early LDS-DMA - load_untracked,

@@ -8,13 +8,17 @@ M, N, K = (int(x) for x in sys.argv[1:4]) if len(sys.argv) > 3 else (50432, 3072
 dt = torch.bfloat16
 x = torch.randn(M, K, device="cuda").to(dt); w = torch.randn(N, K, device="cuda").to(dt)
 y = torch.empty(M, N, device="cuda", dtype=dt)
-for _ in range(3): ops.gemm(x, w, y)
+ACT = int(os.environ.get('ACT', '0'))
+aux = torch.empty(M, N, device='cuda', dtype=dt) if ACT else None
+def run(): ops.gemm(x, w, y, act=ACT, aux_out=aux if ACT == ops.ACT_QGELU else None, aux_in=aux if ACT == ops.ACT_DQGELU else None)
+for _ in range(3): run()
 nb = ((M + 127) // 128) * ((N + 127) // 128)
 dbg = torch.zeros(nb * 8, dtype=torch.int64, device="cuda")
 lib.missm_gemm_set_debug_buffer(dbg.data_ptr())
-ops.gemm(x, w, y); torch.cuda.synchronize()
+run(); torch.cuda.synchronize()
 lib.missm_gemm_set_debug_buffer(None)
 d = dbg.cpu().numpy().reshape(nb, 8)
+d = d[d[:, 0] != 0]; nb = len(d)     # (the 256x256 kernel uses a quarter of the stamp slots)
 t0 = d[:, 0].min()
 start, loop, loop_end, end = [(d[:, i] - t0) / 100.0 for i in range(4)]   # microseconds (100 MHz)
 hw = d[:, 4]
