@@ -911,6 +911,14 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
         }
         attr_set = true;
       }
+      // (s_setprio around the MFMA cluster: +4 % at K = 2304 / 3072 on this tile, -4..5 % at K = 768 - four waves per SIMD
+      //  already interleave; the opposite of the 128x128 kernel, where it helps the short-K shapes)
+      if (variant == 0 || (variant < 0 && K <= 1024)) {
+        auto k0 = gemm_kernel<bf16, false, false, 128, 0, 4>;
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k0), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        hipLaunchKernelGGL(k0, dim3(tmb * tn2), dim3(1024), 128 * 1024, s, g);
+        return missm_check_launch("gemm256");
+      }
       hipLaunchKernelGGL(k, dim3(tmb * tn2), dim3(1024), 128 * 1024, s, g);
       return missm_check_launch("gemm256");
     }
