@@ -881,7 +881,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
       (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU)) {
     const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2;
     const int rounds = (t2 + 255) / 256;
-    const bool fills = t2 >= 192 && t2 * 100 >= rounds * 256 * 75;       // >= 75 % of the last-round-padded grid is real work
+    static const int eff_env = getenv("MISSM_GEMM_BIG_EFF") ? atoi(getenv("MISSM_GEMM_BIG_EFF")) : 75;
+    const bool fills = t2 >= 192 && t2 * 100 >= rounds * 256 * eff_env;  // >= 75 % of the last-round-padded grid is real work
     if (big_env == 1 || fills) {
       // A last round that would be mostly idle goes to the 128x128 kernel instead: the big tiles take the tile rows that fill
       // whole rounds of 256 CUs, the remaining rows are a second, small launch (e.g. N = 768: 591 big tiles = 2.3 rounds ->
