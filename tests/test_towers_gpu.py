@@ -89,6 +89,46 @@ def test_vision_tower_vs_reference_fixture(pkg, name, dtype, tol):
         assert grad_ok(k, mine, g, gtol, dtype), k
 
 
+def test_full_size_vitb16_vs_reference_and_properties(pkg):
+    """BASELINE.json configs[0] at full size on the GPU (ViT-B/16, 224x224, 197 tokens, B = 4): pooled output and a slice of
+    the last hidden state against the fixture captured from the reference (fp32 instantiation 1e-3, bf16 3e-2), then the
+    size-independent properties: batch independence, linearity of the backward in the upstream gradient, and run-to-run
+    reproducibility of the weight gradients (split-K slices are summed in a fixed order)."""
+    fix = load_golden("vitb16_config1")
+    ocfg = O.VisionCfg(**fix["cfg"])
+    params = O.init_tower_params(ocfg, fix["seed_w"])
+    x = vision_inputs(fix, ocfg).cuda()
+    t32 = make_tower(pkg, fix["cfg"], "vision", params, torch.float32)
+    with torch.no_grad():
+        last32, pooled32 = t32(x)
+    assert rel(pooled32, fix["pooled"]) < TOL32 and rel(last32[:, :4, :64], fix["last_hidden_slice"]) < TOL32
+    del t32
+    tower = make_tower(pkg, fix["cfg"], "vision", params, torch.bfloat16)
+    last, pooled = tower(x)
+    assert rel(pooled, fix["pooled"]) < TOLBF and rel(last[:, :4, :64], fix["last_hidden_slice"]) < TOLBF
+    with torch.no_grad():                                   # batch independence: samples do not see each other
+        _, half = tower(x[:2])
+    assert rel(half, pooled[:2]) < 2e-3
+    cot = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(5)).cuda()
+    names = ["encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.11.mlp.fc2.weight", "embeddings.patch_embedding.weight",
+             "encoder.layers.5.mlp.fc1.bias", "post_layernorm.weight"]
+    (pooled * cot).sum().backward()
+    g1 = {k: tower.get_parameter(k).grad.clone() for k in names}
+    _, pooled_b = tower(x)
+    assert torch.equal(pooled_b, pooled)                    # forward is deterministic
+    (pooled_b * (2.0 * cot)).sum().backward()               # gradients are overwritten per backward, and linear in the cotangent
+    for k in names:
+        g2 = tower.get_parameter(k).grad
+        assert rel(g2, 2.0 * g1[k]) < 1e-3, k
+    _, pooled_c = tower(x)
+    (pooled_c * (2.0 * cot)).sum().backward()
+    g3 = {k: tower.get_parameter(k).grad.clone() for k in names[:3]}   # weight gradients (GEMM + ordered split-K reduce):
+    _, pooled_d = tower(x)
+    (pooled_d * (2.0 * cot)).sum().backward()
+    for k in names[:3]:                                     # ... bit-reproducible from run to run
+        assert torch.equal(tower.get_parameter(k).grad, g3[k]), k
+
+
 @pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOLBF)])
 def test_text_tower_vs_fixture(pkg, dtype, tol):
     fix = load_golden("text_tiny")
