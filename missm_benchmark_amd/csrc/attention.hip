@@ -64,7 +64,7 @@ template <bool PW> __device__ __forceinline__ void stage_wait() {
 // PW = false: one workgroup (8 waves) per (sequence, head), tiles dealt over the waves  (S = 197 / 77)
 // PW = true : one WAVE per (sequence, head) with its own LDS slice, no workgroup barrier (time attention, L = T <= 32):
 //             the 8x8 score block rides in one 16x16 MFMA tile; 6 MFMAs per unit instead of ~2000 VALU FMAs per lane.
-template <typename T, int NTP, bool PW>
+template <typename T, int NTP, bool PW, bool CAUSAL>
 __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
@@ -86,6 +86,7 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
   const size_t base = seq_base(a, seq);
   const T* qkv = static_cast<const T*>(a.qkv);
   const int L = a.L;
+  const float sl2 = a.scale * 1.4426950408889634f;   // scale * log2(e)
   constexpr int NWV = PW ? 1 : ANW;           // waves cooperating on one unit
   const int wv = PW ? 0 : wave;               // this wave's index among them
 
@@ -125,12 +126,13 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
 #pragma unroll
       for (int ks = 0; ks < KSQ; ++ks)
         acc = M_::step(lds_frag<T>(ldsK, swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T))), qf[ks], acc);
+      // scores live in the log2 domain (scale * log2(e) folded into one multiply-add: exp2 is the hardware instruction), and
+      // the causal select is compiled in only for the text tower (template flag): the kernel is VALU-issue-bound (~520 VALU vs 56 MFMA per tile)
       const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + 4 * lg + r;
-        float s = acc[r] * a.scale + kb[r];
-        if (a.causal && key > qi) s = kNegInf;
+        float s = acc[r] * sl2 + kb[r];
+        if constexpr (CAUSAL) { if (kt * 16 + 4 * lg + r > qi) s = kNegInf; }
         p[kt][r] = s;
         mx = fmaxf(mx, s);
       }
@@ -142,11 +144,11 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
 #pragma unroll
     for (int kt = 0; kt < NTP; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { p[kt][r] = __expf(p[kt][r] - mx); sum += p[kt][r]; }
+      for (int r = 0; r < 4; ++r) { p[kt][r] = __builtin_amdgcn_exp2f(p[kt][r] - mx); sum += p[kt][r]; }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
     const float inv = 1.0f / sum;
-    if (a.lse && qvalid && lg == 0) a.lse[((size_t)seq * a.H + h) * L + qi] = mx + __logf(sum);
+    if (a.lse && qvalid && lg == 0) a.lse[((size_t)seq * a.H + h) * L + qi] = (mx + __log2f(sum)) * 0.6931471805599453f;
 
     Frag pf[NU];
 #pragma unroll
@@ -176,7 +178,7 @@ __device__ __forceinline__ float frag_dot(f32x4 x, f32x4 y, float s) { return s 
 // the probabilities / score gradients of a tile row can then be packed into MFMA operand fragments as they are produced,
 // two 16-key tiles at a time, instead of living in 2 x NTP fp32 tiles until the row sum is known - 216 -> <= 128 VGPRs at
 // S = 197, i.e. two 8-wave workgroups per CU instead of one.
-template <typename T, int NTP, bool PW>
+template <typename T, int NTP, bool PW, bool CAUSAL>
 __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
@@ -206,13 +208,14 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
   const T* fout = static_cast<const T*>(a.out);
   T* dqkv = static_cast<T*>(a.dqkv);
   const int L = a.L;
+  const float sl2 = a.scale * 1.4426950408889634f;   // scale * log2(e); lse is rescaled to the log2 domain on its way into LDS
   const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
 
   stage_head<T, RBv, NWV>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wv);
   stage_head<T, RBv, NWV>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, lane, wv);
   for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS) {
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
-    lseL[k] = k < L ? lse[k] : __builtin_huge_valf();
+    lseL[k] = k < L ? lse[k] * 1.4426950408889634f : __builtin_huge_valf();
   }
   const int nt = (L + 15) / 16;
   constexpr int MAXQ = (NTP + NWV - 1) / NWV;   // query / key tiles per wave
@@ -291,12 +294,12 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
           dp = M_::step(lds_frag<T>(X1, off), dof[ks], dp);
         }
         const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+        // (the softmax scale is applied once to the dQ / dK accumulators instead of to every dS element)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int key = kt * 16 + 4 * lg + r;
-          float pv = __expf(sc[r] * a.scale + kb[r] - lq);
-          if (a.causal && key > qi) pv = 0.f;
-          dsv[c][r] = pv * (dp[r] - dsum) * a.scale;
+          float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kb[r] - lq);
+          if constexpr (CAUSAL) { if (kt * 16 + 4 * lg + r > qi) pv = 0.f; }
+          dsv[c][r] = pv * (dp[r] - dsum);
         }
       }
       dsf[u] = M_::from_acc(dsv[0], dsv[CT - 1]);
@@ -306,6 +309,7 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int u = 0; u < NU; ++u) acc = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf[u], acc);
+      acc *= a.scale;
       if (qvalid) store4(dqkv + qrow * a.ld + h * HD + dt * 16 + 4 * lg, acc);
     }
   }
@@ -369,11 +373,10 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
         const f32x4 dq = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int q = qt * 16 + 4 * lg + r;
-          float pv = __expf(sc[r] * a.scale + kb - lq[r]);
-          if (a.causal && key > q) pv = 0.f;
+          float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kb - lq[r]);
+          if constexpr (CAUSAL) { if (key > qt * 16 + 4 * lg + r) pv = 0.f; }
           pv4[c][r] = pv;
-          dsv[c][r] = pv * (dp[r] - dq[r]) * a.scale;
+          dsv[c][r] = pv * (dp[r] - dq[r]);
         }
       }
       pf[u] = M_::from_acc(pv4[0], pv4[CT - 1]);
@@ -387,6 +390,7 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
         dv = M_::step(TrFrag<T, RBv>::load(X1, u * M_::KS, dt * 16, lane), pf[u], dv);
         dk = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf[u], dk);
       }
+      dk *= a.scale;
       if (kin) {
         store4(dqkv + krow * a.ld + a.d + h * HD + dt * 16 + 4 * lg, dk);
         store4(dqkv + krow * a.ld + 2 * a.d + h * HD + dt * 16 + 4 * lg, dv);
@@ -602,7 +606,8 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
     const int units = a.nseq * a.H;
     dim3 grid((units + ANW - 1) / ANW), block(ATHREADS);
     size_t shmem = (size_t)ANW * (2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1));
-    auto k = BWD ? attn_bwd_mfma_kernel<T, NTP, true> : attn_fwd_mfma_kernel<T, NTP, true>;
+    auto k = a.causal ? (BWD ? attn_bwd_mfma_kernel<T, NTP, true, true> : attn_fwd_mfma_kernel<T, NTP, true, true>)
+                      : (BWD ? attn_bwd_mfma_kernel<T, NTP, true, false> : attn_fwd_mfma_kernel<T, NTP, true, false>);
     int rc = launch_dyn(k, grid, block, shmem, s, "attn_wave"); if (rc) return rc;
     hipLaunchKernelGGL(k, grid, block, shmem, s, a);
     return missm_check_launch("attn_wave");
@@ -627,7 +632,8 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
 #define MISSM_MFMA(NTP)                                                                                     \
   do {                                                                                                      \
     size_t shmem = (size_t)2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1);              \
-    auto k = BWD ? attn_bwd_mfma_kernel<T, NTP, false> : attn_fwd_mfma_kernel<T, NTP, false>;                  \
+    auto k = a.causal ? (BWD ? attn_bwd_mfma_kernel<T, NTP, false, true> : attn_fwd_mfma_kernel<T, NTP, false, true>)     \
+                      : (BWD ? attn_bwd_mfma_kernel<T, NTP, false, false> : attn_fwd_mfma_kernel<T, NTP, false, false>); \
     int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                            \
     hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                         \
   } while (0)
