@@ -10,6 +10,7 @@
 //           * backward accumulates straight into the fp32 residual-gradient stream and reduces
 //             dgamma/dbeta per workgroup before one 256-byte-contiguous atomic per wave.
 #include "common.h"
+#include <stdlib.h>
 #include "missm_internal.h"
 #include <type_traits>
 
@@ -215,8 +216,9 @@ extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, c
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd: cols must be a positive multiple of 4");
   LnBwdArgs a{dy, dy_div > 0 ? dy_div : 1, dy_scale, x, in_mul > 0 ? in_mul : 1, in_off, mean, rstd, gamma, dx, accumulate,
               dgamma, dbeta, rows, cols, dx_cast};
+  static const int cap = getenv("MISSM_LN_BLOCKS") ? atoi(getenv("MISSM_LN_BLOCKS")) : 1024;
   int blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > cap) blocks = cap;
   dim3 grid(blocks), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_ch<void>(cols, [&](auto ch) {
