@@ -53,6 +53,32 @@ class _Projection(nn.Module):
         return hnn._LinearFn.apply(x, self.weight, None, False, None, 0)
 
 
+def merge_lora_state_dict(sd: Dict[str, torch.Tensor], lora_r: int, lora_alpha: float) -> Dict[str, torch.Tensor]:
+    """Released LanguageBind checkpoints carry the encoder wrapped by peft (reference image/modeling_image.py:775-793:
+    ``get_peft_model(vision_model.encoder, LoraConfig(r, lora_alpha, target_modules=q/k/v/out_proj ...))``), i.e. keys
+    ``...encoder.base_model.model.layers.N.self_attn.q_proj.{base_layer.weight, lora_A.default.weight, lora_B.default.weight}``.
+    The towers here keep plain weights: fold every adapter into its base matrix, W + (lora_alpha / r) * B @ A - the same
+    function of the input as the unmerged peft forward (lora_dropout is inactive in eval) - and strip the wrapper prefixes.
+    Host-side, once, at load time."""
+    scale = float(lora_alpha) / float(lora_r) if lora_r else 0.0
+    out: Dict[str, torch.Tensor] = {}
+    lora = {}
+    for k, v in sd.items():
+        k = k.replace(".base_model.model.", ".")
+        if ".lora_A." in k or ".lora_B." in k:
+            stem, which = (k.split(".lora_A.")[0], "A") if ".lora_A." in k else (k.split(".lora_B.")[0], "B")
+            lora.setdefault(stem, {})[which] = v
+            continue
+        if ".lora_dropout." in k or ".lora_embedding_" in k:
+            continue
+        out[k.replace(".base_layer.", ".")] = v
+    for stem, ab in lora.items():
+        if "A" not in ab or "B" not in ab or stem + ".weight" not in out:
+            raise KeyError(f"incomplete LoRA adapter for {stem}")
+        out[stem + ".weight"] = out[stem + ".weight"].float() + scale * (ab["B"].float() @ ab["A"].float())
+    return out
+
+
 class LanguageBindModel(nn.Module):
     """One modality's CLIP pair (reference ``LanguageBind<Modality>``, image/modeling_image.py:734-768): vision tower,
     text tower, the two bias-free projections and ``logit_scale``."""
@@ -92,7 +118,11 @@ class LanguageBindModel(nn.Module):
                 for fn in ("pytorch_model.bin", "model.pt", "model.pth"):
                     p = os.path.join(root, fn)
                     if os.path.exists(p):
-                        model.load_state_dict(torch.load(p, map_location="cpu"), strict=False)
+                        sd = torch.load(p, map_location="cpu")
+                        if any(".lora_A." in k for k in sd):
+                            vraw = raw.get("vision_config", {})
+                            sd = merge_lora_state_dict(sd, int(vraw.get("lora_r", 2)), float(vraw.get("lora_alpha", 16)))
+                        model.load_state_dict(sd, strict=False)
                         break
                 return model
         return cls(**kw)
