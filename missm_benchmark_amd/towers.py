@@ -48,6 +48,7 @@ class TowerConfig:
     add_time_attn: bool = False
     num_frames: int = 1
     temporal_mlp: bool = False
+    force_patch_dropout: float = 0.0     # PatchDropout (image/modeling_image.py:30-63): identity at 0 / in eval; > 0 is rejected
     # text (configuration_image.py:70-105)
     vocab_size: int = 49408
     max_position_embeddings: int = 77
@@ -73,6 +74,9 @@ class ClipTower(nn.Module):
             raise ValueError("head_dim must be a multiple of 8")
         if c.kind == "vision" and (c.patch_size % 4 or c.image_size % c.patch_size):
             raise ValueError("patch_size must be a multiple of 4 and divide image_size")
+        if c.kind == "vision" and c.force_patch_dropout:
+            raise NotImplementedError("force_patch_dropout > 0 (random token dropping in training, image/modeling_image.py:30-63) is not "
+                                      "implemented; the default configuration uses 0")
         self.config = c
         self.compute_dtype = compute_dtype
         d, f = c.hidden_size, c.intermediate_size

@@ -108,3 +108,12 @@ def test_lora_checkpoint_merge_matches_unmerged_adapter(tmp_path):
     loaded = LanguageBindImage.from_pretrained("LanguageBind/LanguageBind_Image", cache_dir=str(tmp_path), seed=9)
     for k, v in loaded.state_dict().items():
         assert torch.allclose(v, merged[k], atol=1e-6), k
+
+
+def test_unsupported_config_options_fail_loudly():
+    import pytest
+    from missm_benchmark_amd.towers import ClipTower, TowerConfig
+    tiny = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=32, patch_size=16)
+    with pytest.raises(NotImplementedError, match="force_patch_dropout"):
+        ClipTower(TowerConfig(kind="vision", force_patch_dropout=0.5, **tiny))
+    ClipTower(TowerConfig(kind="vision", force_patch_dropout=0.0, **tiny))
