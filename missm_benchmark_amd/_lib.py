@@ -43,6 +43,7 @@ SIGNATURES = {
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
+ABI_VERSION = 2     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 
@@ -67,7 +68,7 @@ def load():
         fn = getattr(lib, name)
         fn.argtypes = args
         fn.restype = res
-    if lib.missm_abi_version() != 2:
+    if lib.missm_abi_version() != ABI_VERSION:
         raise MissmError("libmissm_hip.so ABI version mismatch; rebuild")
     _lib = lib
     return lib
