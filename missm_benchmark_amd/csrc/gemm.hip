@@ -40,7 +40,6 @@ struct GemmArgs {
   float* ws;                // split-K workspace: [splitk][tiles][16][256] float4 partial accumulators (register order)
   unsigned long long* dbg;  // diagnostic builds only: per-workgroup {start, loop start, loop end, end, hw id} stamps (100 MHz clock)
   int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
-  int exp_flags;            // TEMPORARY timing experiments (wrong results): 1 = no staging in the loop
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
 };
 
@@ -510,7 +509,7 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
     // the fragment reads: the compiler cannot see that ds_read_b64_tr_b16 (an intrinsic without memory operands) does not
     // alias the DMA's LDS writes and would put s_waitcnt vmcnt(0) - the whole global-load latency - in front of the reads.
     constexpr bool STAGE_LATE = VAR == 2 && (TA || TB);
-    if (!STAGE_LATE && kt + 1 < nk && !(g.exp_flags & 1)) stage(buf ^ 1, kbeg + (kt + 1) * BK);
+    if (!STAGE_LATE && kt + 1 < nk) stage(buf ^ 1, kbeg + (kt + 1) * BK);
     const char* la = ldsA + buf * TILE_BYTES;
     const char* lb = ldsB + buf * TILE_BYTES;
     if constexpr (VAR == 2) {
@@ -839,8 +838,6 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   static const int group_m_env = getenv("MISSM_GEMM_GROUP_M") ? atoi(getenv("MISSM_GEMM_GROUP_M")) : 0;
   g.group_m = 1;   // set once the tile grid is known
   g.dbg = missm_gemm_debug_buffer;
-  static const int exp_env = getenv("MISSM_GEMM_EXP") ? atoi(getenv("MISSM_GEMM_EXP")) : 0;
-  g.exp_flags = exp_env;
   static const int variant = getenv("MISSM_GEMM_VARIANT") ? atoi(getenv("MISSM_GEMM_VARIANT")) : -1;   // scheduling experiments
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
