@@ -218,15 +218,29 @@ def main():
         enc.parallel_streams = False
         step(); barrier()
         prof = []
+        aprof = []
         ops.GEMM_PROFILE = prof
+        ops.ATTN_PROFILE = aprof
         t1 = time.perf_counter()
         for _ in range(2):
             step()
         barrier()
         replay_ms = (time.perf_counter() - t1) / 2 * 1e3
         ops.GEMM_PROFILE = None
+        ops.ATTN_PROFILE = None
         enc.parallel_streams = True
 
+    roof_attn = None
+    if not args.no_roofline and not inline_prof and aprof:
+        # the north star's second figure: the attention kernels (QK^T / softmax / PV and their backward) - stand-alone they are
+        # HBM-bound (98.5 FLOP/B against a ridge of 310), so the bound is HBM; the MFMA fraction is reported next to it
+        ams = sum(p[0].elapsed_time(p[1]) for p in aprof)
+        afl, aby = sum(p[2] for p in aprof), sum(p[3] for p in aprof)
+        roof_attn = {"kernel": "attn_fwd_mfma_kernel / attn_bwd_mfma_kernel (all attention launches of a step)", "bound": "hbm",
+                     "achieved": round(aby / (ams * 1e-3) / 1e9, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(aby / (ams * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
+                     "mfma_TFLOP_per_s": round(afl / (ams * 1e-3) / 1e12, 1), "mfma_frac": round(afl / (ams * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                     "launches": len(aprof), "attention_ms_per_step": round(ams / 2, 2)}
     roof = None
     if prof:
         flops = sum(p[2] for p in prof)
@@ -256,6 +270,8 @@ def main():
                           "modalities": modalities, "missing_ratio": args.missing, "params": engine.num_parameters(),
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4)},
                "roofline": roof}
+        if roof_attn is not None:
+            out["roofline_attention"] = roof_attn
         if world == 1 and not args.no_cpu_baseline and "language" not in modalities:
             out["cpu_baseline"] = cpu_baseline(modalities, args.cpu_batch)
         print(json.dumps(out), flush=True)

@@ -45,6 +45,7 @@ def _req(t: torch.Tensor, name: str):
 
 
 GEMM_PROFILE = None  # bench.py sets this to a list: (start_event, end_event, flops) per launch
+ATTN_PROFILE = None  # likewise for the attention launches: (start_event, end_event, flops, algorithmic bytes, 'fwd' | 'bwd')
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool = False, trans_b: bool = False, bias=None,
@@ -171,8 +172,16 @@ def attention_fwd(qkv, out, lse, nseq, L, H, hd, *, seq_div=1, seq_outer=None, s
         raise _lib.MissmError("attention_fwd: key_mask must be int32 [nseq, L]")
     if lse is not None and lse.numel() < nseq * H * L:
         raise _lib.MissmError("attention_fwd: lse too small")
+    prof = ATTN_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("missm_attention_fwd", qkv.data_ptr(), out.data_ptr(), _p(lse), nseq, L, H, hd, qkv.stride(0), out.stride(0),
               seq_div, seq_outer, seq_inner, tok_stride, int(causal), _p(key_mask), float(scale), dt(qkv), _s())
+    if prof is not None:
+        e1.record()
+        es = qkv.element_size()
+        prof.append((e0, e1, 4.0 * nseq * H * L * L * hd, nseq * L * H * hd * 4 * es, "fwd"))      # read q,k,v + write out
     return out
 
 
@@ -184,9 +193,17 @@ def attention_bwd(qkv, out, dout, lse, dqkv, nseq, L, H, hd, *, seq_div=1, seq_o
     if min(qkv.shape[0], dout.shape[0], out.shape[0], dqkv.shape[0]) < rows_needed or dqkv.stride(0) != qkv.stride(0) or \
             out.stride(0) != dout.stride(0) or out.dtype != qkv.dtype:
         raise _lib.MissmError("attention_bwd: row addressing exceeds the buffers")
+    prof = ATTN_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     _lib.call("missm_attention_bwd", qkv.data_ptr(), out.data_ptr(), dout.data_ptr(), lse.data_ptr(), dqkv.data_ptr(), nseq, L, H, hd,
               qkv.stride(0), dout.stride(0), seq_div, seq_outer, seq_inner, tok_stride, int(causal), _p(key_mask), float(scale),
               dt(qkv), _s())
+    if prof is not None:
+        e1.record()
+        es = qkv.element_size()
+        prof.append((e0, e1, 10.0 * nseq * H * L * L * hd, nseq * L * H * hd * 8 * es, "bwd"))     # read q,k,v,o,do + write dq,dk,dv
     return dqkv
 
 
