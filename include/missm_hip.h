@@ -155,6 +155,11 @@ int missm_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, lon
  * reads p, g, m, v; writes p, m, v. grad_scale multiplies g first (1/world_size for an all-reduce SUM). */
 int missm_adam_step(float* p, const float* g, float* m, float* v, long n, int step, float lr, float beta1, float beta2, float eps,
                     float weight_decay, float grad_scale, void* stream);
+/* The same step for the weight matrices listed in a missm_cast_weights_batched tile table, fused with the refresh of their
+ * `dtype` copies (W and W^T): g, m, v are addressed at g_off / m_off / v_off FLOATS from each tile's master pointer (flat
+ * buffers parallel to the master buffer).  Saves re-reading the updated weights for the separate refresh. */
+int missm_adam_cast_batched(const void* tiles, int ntiles, long g_off, long m_off, long v_off, int step, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, float grad_scale, int dtype, void* stream);
 
 #ifdef __cplusplus
 }

@@ -39,6 +39,7 @@ SIGNATURES = {
     "missm_dropout_fwd": [P, P, P, L, F, U64, P],
     "missm_dropout_bwd": [P, P, P, L, F, P],
     "missm_adam_step": [P, P, P, P, L, I, F, F, F, F, F, F, P],
+    "missm_adam_cast_batched": [P, I, L, L, L, I, F, F, F, F, F, F, I, P],
 }
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}

@@ -14,6 +14,7 @@
 #include "mma.h"
 #include "missm_internal.h"
 #include <stdlib.h>
+#include <math.h>
 #include <mutex>
 #include <unordered_map>
 
@@ -780,6 +781,44 @@ __global__ __launch_bounds__(256) void cast_weights_batched_kernel(const CastTil
   }
 }
 
+// The optimizer step of a tower's weight matrices fused with the refresh of their compute-dtype copies: one 64x64 tile per
+// workgroup reads p, g, m, v, applies Adam (same arithmetic as adam_kernel, misc.hip), writes p, m, v and the bf16 W / W^T
+// tiles - the separate refresh would read the 4 bytes/parameter of p once more.  g, m, v live in flat buffers parallel to
+// the master buffer: the same element offset, at a fixed distance (in floats) from it.
+struct AdamTileArgs { long g_off, m_off, v_off; float lr_bc1, inv_sqrt_bc2, beta1, beta2, eps, wd, gscale; };
+template <typename T>
+__global__ __launch_bounds__(256) void adam_cast_batched_kernel(const CastTile* __restrict__ tiles, AdamTileArgs a) {
+  __shared__ float tile[64][65];
+  const CastTile t = tiles[blockIdx.x];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  float* src = const_cast<float*>(t.src);
+  T* dst = static_cast<T*>(t.dst);
+  T* dst_t = static_cast<T*>(t.dst_t);
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = t.r0 + ty + 4 * i, c = t.c0 + tx;
+    float pv = 0.f;
+    if (r < t.R && c < t.C) {
+      float* p = src + (size_t)r * t.C + c;
+      pv = *p;
+      const float gg = p[a.g_off] * a.gscale + a.wd * pv;
+      const float mv = a.beta1 * p[a.m_off] + (1.f - a.beta1) * gg;
+      const float vv = a.beta2 * p[a.v_off] + (1.f - a.beta2) * gg * gg;
+      pv -= a.lr_bc1 * mv / (sqrtf(vv) * a.inv_sqrt_bc2 + a.eps);
+      *p = pv; p[a.m_off] = mv; p[a.v_off] = vv;
+      if (dst) dst[(size_t)r * t.C + c] = from_f32<T>(pv);
+    }
+    tile[ty + 4 * i][tx] = pv;
+  }
+  if (!dst_t) return;
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = t.c0 + ty + 4 * i, r = t.r0 + tx;
+    if (c < t.C && r < t.R) dst_t[(size_t)c * t.R + r] = from_f32<T>(tile[tx][ty + 4 * i]);
+  }
+}
+
 }  // namespace missm
 
 using namespace missm;
@@ -993,6 +1032,17 @@ extern "C" int missm_cast_weights_batched(const void* tiles, int ntiles, int dty
   if (dtype == kBF16) hipLaunchKernelGGL(cast_weights_batched_kernel<bf16>, dim3(ntiles), dim3(256), 0, s, (const CastTile*)tiles);
   else hipLaunchKernelGGL(cast_weights_batched_kernel<float>, dim3(ntiles), dim3(256), 0, s, (const CastTile*)tiles);
   return missm_check_launch("cast_weights_batched");
+}
+
+extern "C" int missm_adam_cast_batched(const void* tiles, int ntiles, long g_off, long m_off, long v_off, int step, float lr, float beta1,
+                                       float beta2, float eps, float weight_decay, float grad_scale, int dtype, void* stream) {
+  MISSM_CHECK_ARG(tiles && ntiles > 0 && step >= 1, "adam_cast_batched: bad args");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  AdamTileArgs a{g_off, m_off, v_off, (float)(lr / bc1), (float)(1.0 / sqrt(bc2)), beta1, beta2, eps, weight_decay, grad_scale};
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  if (dtype == kBF16) hipLaunchKernelGGL(adam_cast_batched_kernel<bf16>, dim3(ntiles), dim3(256), 0, s, (const CastTile*)tiles, a);
+  else hipLaunchKernelGGL(adam_cast_batched_kernel<float>, dim3(ntiles), dim3(256), 0, s, (const CastTile*)tiles, a);
+  return missm_check_launch("adam_cast_batched");
 }
 
 extern "C" int missm_cast_weight(const float* src, void* dst, void* dst_t, int R, int C, int dtype, void* stream) {

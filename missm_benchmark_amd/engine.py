@@ -14,6 +14,8 @@ of the collective logic (tests), where Adam falls back to nothing - there is no 
 """
 from __future__ import annotations
 
+import os
+
 from typing import List, Optional
 
 import torch
@@ -22,6 +24,9 @@ from torch import nn
 
 from . import ops
 from .towers import ClipTower
+
+
+_FUSED_UPDATE = os.environ.get("MISSM_FUSED_ADAM", "1") != "0"   # A/B switch: Adam fused with the weight-shadow refresh
 
 
 class FlatGroup:
@@ -157,8 +162,17 @@ class TrainEngine:
         if key not in self._state:
             self._state[key] = (torch.zeros_like(master), torch.zeros_like(master))
         m, v = self._state[key]
-        ops.adam_step(master, grad, m, v, self.step_count + 1, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                      grad_scale=1.0 / self.world)
+        hp = (self.step_count + 1, self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
+        if _FUSED_UPDATE and t is not None and t.fused_update_ready():
+            # weight matrices: Adam fused with the refresh of their compute-dtype copies (one pass over p, g, m, v);
+            # everything else (biases, LayerNorm, embeddings: the tail of the flat buffer): the plain fused Adam
+            t.adam_and_refresh(grad, m, v, *hp, grad_scale=1.0 / self.world)
+            lo = t.vec_start()
+            if lo < master.numel():
+                ops.adam_step(master[lo:], grad[lo:], m[lo:], v[lo:], *hp, grad_scale=1.0 / self.world)
+            t._grad_fresh = False
+            return
+        ops.adam_step(master, grad, m, v, *hp, grad_scale=1.0 / self.world)
         if t is not None:
             t.mark_dirty()
             t._grad_fresh = False

@@ -289,6 +289,16 @@ def dropout_bwd(dy, mask, dx, p):
     return dx
 
 
+def adam_cast_batched(table, ntiles, master, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale, dtype_code):
+    """Adam on the weight matrices of a cast-tile table + refresh of their compute-dtype copies; g, m, v are flat buffers
+    parallel to ``master`` (same element offsets)."""
+    if not (g.numel() == m.numel() == v.numel() == master.numel()) or g.dtype != torch.float32:
+        raise _lib.MissmError("adam_cast_batched: g, m, v must be fp32 buffers parallel to the master buffer")
+    off = lambda t: (t.data_ptr() - master.data_ptr()) // 4   # noqa: E731
+    _lib.call("missm_adam_cast_batched", table.data_ptr(), ntiles, off(g), off(m), off(v), int(step), float(lr), float(beta1),
+              float(beta2), float(eps), float(weight_decay), float(grad_scale), dtype_code, _s())
+
+
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     _lib.call("missm_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(step), float(lr),
               float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _s())

@@ -220,6 +220,22 @@ class ClipTower(nn.Module):
         ops.cast_weights_batched(self._cast_table, self._cast_tiles, ops.F32 if T == torch.float32 else ops.BF16)
         self._shadow_version = st.master._version
 
+    # ---- optimizer step fused with the shadow refresh (engine.TrainEngine) ----------------------------------------
+    def vec_start(self) -> int:
+        return self._store.vec_start
+
+    def fused_update_ready(self) -> bool:
+        """shadows exist and are current: the weight matrices may be updated through the cast-tile table"""
+        st = self._store
+        return bool(self._shadow) and self._shadow_version == st.master._version and st.master.is_cuda
+
+    def adam_and_refresh(self, grad, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+        st = self._store
+        T = self.compute_dtype
+        ops.adam_cast_batched(self._cast_table, self._cast_tiles, st.master, grad, m, v, step, lr, beta1, beta2, eps, weight_decay,
+                              grad_scale, ops.F32 if T == torch.float32 else ops.BF16)
+        # (the kernels write through raw pointers: the master's version counter, hence the shadows' validity, is unchanged)
+
     def _ensure_ready(self):
         st = self._store
         if not st.master.is_cuda:

@@ -71,7 +71,8 @@ def _worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         model = _model(seed=7 * (rank + 1)).cuda()          # different init per rank: the engine must broadcast rank 0's
         out = _train(model, _batch(rank))
-        q.put((rank, out, ""))
+        # by value (numpy), not as shared-memory tensors: the parent may fetch the item after this process has exited
+        q.put((rank, tuple({k: v.numpy() for k, v in d.items()} for d in out), ""))
         dist.destroy_process_group()
     except Exception:  # pragma: no cover
         import traceback
@@ -93,6 +94,7 @@ def test_two_ranks_match_single_process_on_concatenated_batch():
         p.join(timeout=60)
     for r in res:
         assert r[2] == "", r[2]
+    res = [(r[0], tuple({k: torch.from_numpy(v) for k, v in d.items()} for d in r[1]), r[2]) for r in res]
     for k in KEYS:
         assert torch.equal(res[0][1][1][k], res[1][1][1][k]), f"ranks diverged on {k}"
         assert torch.equal(res[0][1][0][k], res[1][1][0][k]), f"reduced gradients differ on {k}"

@@ -206,6 +206,42 @@ def test_colsum_groups_and_cast(ops, dtype):
     assert rel(wd, w.to(dtype).float()) == 0 and rel(wt, w.t().to(dtype).float()) == 0
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_adam_fused_with_shadow_refresh_equals_two_passes(ops, dtype):
+    """missm_adam_cast_batched == missm_adam_step followed by missm_cast_weights_batched (ragged 64x64 tiles); equal up to
+    the contraction of multiply-adds, which the compiler is free to choose differently in the two kernels"""
+    shapes = [(100, 72), (64, 192), (130, 8)]
+    total = sum(r * c for r, c in shapes) + 64
+    g = torch.Generator().manual_seed(3)
+    master = torch.randn(total, generator=g).cuda()
+    grad, m, v = (torch.randn(total, generator=g).cuda() * s for s in (0.1, 0.01, 0.0))
+    v = (torch.rand(total, generator=g) * 1e-3).cuda()
+    code = ops.F32 if dtype == torch.float32 else ops.BF16
+
+    def build(buf):
+        entries, views, off = [], [], 0
+        for r, c in shapes:
+            src = buf[off:off + r * c].view(r, c)
+            w = None if dtype == torch.float32 else torch.zeros(r, c, device="cuda", dtype=dtype)
+            wt = torch.zeros(c, r, device="cuda", dtype=dtype)
+            entries.append((src, w, wt)); views.append((w, wt)); off += r * c
+        table, n = ops.build_cast_table(entries, buf.device)
+        return table, n, views, off
+
+    a = [t.clone() for t in (master, grad, m, v)]
+    b = [t.clone() for t in (master, grad, m, v)]
+    ta, na, va, used = build(a[0])
+    ops.adam_step(a[0][:used], a[1][:used], a[2][:used], a[3][:used], 3, 1e-2, 0.9, 0.999, 1e-8, 0.01, grad_scale=0.5)
+    ops.cast_weights_batched(ta, na, code)
+    tb, nb, vb, _ = build(b[0])
+    ops.adam_cast_batched(tb, nb, b[0], b[1], b[2], b[3], 3, 1e-2, 0.9, 0.999, 1e-8, 0.01, 0.5, code)
+    for x, y in zip(a, b):
+        assert rel(x[:used], y[:used]) < 1e-6
+    assert torch.equal(b[0][used:], master[used:])            # nothing outside the listed matrices is touched
+    for (wa, wta), (wb, wtb) in zip(va, vb):
+        assert rel(wta, wtb) < TOL[dtype] and (wa is None or rel(wa, wb) < TOL[dtype])
+
+
 # ------------------------------------------------------------------ LayerNorm
 @pytest.mark.parametrize("odt", DTYPES)
 @pytest.mark.parametrize("rows,cols", [(50, 768), (7, 64), (33, 256), (9, 1024)])
