@@ -505,7 +505,8 @@ class ClipTower(nn.Module):
             dx = torch.empty(rows, d, **f32)
             ops.layernorm_bwd(dh, x0, m0, r0, st.view("pre_layrnorm.weight"), dx, g("pre_layrnorm.weight"), g("pre_layrnorm.bias"),
                               rows, d, accumulate=False)
-            ops.colsum(dx, g("embeddings.position_embedding.weight"), div=1, mod=S, R=rows)
+            # position-embedding gradient: sum over frames of dx[n, s, :] = a plain column sum of dx viewed as [N, S*d]
+            ops.colsum(dx.view(N, S * d), g("embeddings.position_embedding.weight").view(S * d), R=N)
             ops.colsum(dx.view(N, S * d)[:, :d], g("embeddings.class_embedding"), R=N)
             P = S - 1
             dpe = torch.empty(N * P, d, device=dev, dtype=T)
