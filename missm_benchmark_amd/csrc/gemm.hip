@@ -963,7 +963,11 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
-  const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? 2 : (K > 1024 ? 2 : 1));
+  // k-major (dW / NN) forms: variant 1 (per-K-step fragments through untracked reads behind an early LDS-DMA, 147 VGPRs) is
+  // 3-6 % slower than variant 2 (all fragments first, LDS-DMA after them, 173 VGPRs) when the GEMM has the chip to itself,
+  // but the whole step is 0.85 % faster with it when two streams share the chip (385.7 vs 382.5 samples/s, same box)
+  static const int var_tn = getenv("MISSM_GEMM_VAR_TN") ? atoi(getenv("MISSM_GEMM_VAR_TN")) : 1;
+  const int var = variant >= 0 ? variant : ((trans_a || trans_b) ? var_tn : (K > 1024 ? 2 : 1));
 #define MISSM_GEMM_LAUNCH(T, TA, TB)                                                                       \
   do {                                                                                                     \
     if (var == 1) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 1>), grid, block, 64 * 1024, s, g);  \
