@@ -886,7 +886,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   const int bk = dtype == kBF16 ? 64 : 32;
   static const int big_env = getenv("MISSM_GEMM_BIG") ? atoi(getenv("MISSM_GEMM_BIG")) : -1;   // 0 never, 1 whenever legal
   const int tiles = g.tiles_m * g.tiles_n;
-  const int fill = 512;   // workgroups that fill the chip once (2 per CU)
+  static const int fill_env = getenv("MISSM_GEMM_FILL") ? atoi(getenv("MISSM_GEMM_FILL")) : 512;
+  const int fill = fill_env;   // workgroups that fill the chip once (2 per CU)
   if (splitk <= 0) {  // auto: fill the chip exactly ONCE (2 workgroups x 256 CUs) - one resident wave of blocks, no tail.
     // Measured (dW shapes, tiles x splits): 144x3 = 432 -> 427-596 TFLOP/s, 144x4 = 576 -> 280-420 (a second, nearly empty
     // round), 36x12 -> 506 vs 36x8 -> 379; fewer splits also means fewer fp32 atomics (1.3 TB/s chip-wide).
