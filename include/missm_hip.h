@@ -138,10 +138,17 @@ int missm_small_linear_fwd(const float* x, const float* w, const float* bias, fl
                            const long* row_code, long code, const float* x_sub, int accumulate, void* stream);
 /* dx[b,i] (= or +=), dw[o,i] (=), dbias[o] (=) for the layer above; dy (row stride lddy) is masked by row_code/code and,
  * when relu_y is given, by relu_y > 0.  With x_sub the masked rows still feed dw / dbias (their input was x_sub); only
- * their dx is zero. */
+ * their dx is zero.  accumulate_dw: dw / dbias += (a layer applied to several modalities). */
 int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
                            float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
-                           int accumulate_dx, void* stream);
+                           int accumulate_dx, int accumulate_dw, void* stream);
+/* Channel-attention gate of the intra-modality attention head (src/model/baseline.py:198-201):
+ * y[b,f] (= or +=) row b missing ? 0 : d[b,f] * sigmoid(pre[b,f]); d has row stride ldd.  Backward: dd (stride lddd, = or +=)
+ * and dpre, both zero for missing rows. */
+int missm_gate_fwd(const float* d, int ldd, const float* pre, float* y, int B, int F, const long* row_code, long code,
+                   int accumulate, void* stream);
+int missm_gate_bwd(const float* dy, const float* d, int ldd, const float* pre, float* dd, int lddd, float* dpre, int B, int F,
+                   const long* row_code, long code, int accumulate_dd, void* stream);
 /* y = x / ||x||_2 * scale   (languagebind/__init__.py:80-83) and its backward. */
 int missm_l2norm_scale_fwd(const float* x, float* y, int B, int D, float scale, void* stream);
 int missm_l2norm_scale_bwd(const float* dy, const float* x, float* dx, int B, int D, float scale, void* stream);

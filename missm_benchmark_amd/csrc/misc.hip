@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
 __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                              const float* __restrict__ relu_y, float* __restrict__ dw,
                                                              float* __restrict__ dbias, int B, int I, int O, int lddy,
-                                                             const long* __restrict__ row_code, long code, const float* __restrict__ x_sub) {
+                                                             const long* __restrict__ row_code, long code, const float* __restrict__ x_sub,
+                                                             int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)O * I) return;
   const int o = idx / I, i = idx % I;
@@ -151,8 +152,39 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
     acc += g * (subst ? x_sub[i] : x[(long)b * I + i]);
     accb += g;
   }
-  dw[idx] = acc;
-  if (dbias && i == 0) dbias[o] = accb;
+  dw[idx] = accumulate ? dw[idx] + acc : acc;          // accumulate: a layer shared by several modalities (channel attention)
+  if (dbias && i == 0) dbias[o] = accumulate ? dbias[o] + accb : accb;
+}
+
+// channel-attention gate of the intra-modality attention head (src/model/baseline.py:198-201):
+//   y[b, f] (+)= row b missing ? 0 : d[b, f] * sigmoid(pre[b, f])          d has row stride ldd (a slice of [d | fusion_repr])
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* __restrict__ d, int ldd, const float* __restrict__ pre,
+                                                      float* __restrict__ y, int B, int F, const long* __restrict__ row_code, long code,
+                                                      int accumulate) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * F) return;
+  const int b = idx / F, f = idx % F;
+  float v = 0.f;
+  if (!(row_code && row_code[b] == code)) v = d[(long)b * ldd + f] / (1.f + __expf(-pre[idx]));
+  y[idx] = accumulate ? y[idx] + v : v;
+}
+// dd[b, f] (+)= dy * g ; dpre[b, f] = dy * d * g * (1 - g) ; both 0 for a missing row.  dd has row stride lddd.
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ d, int ldd,
+                                                      const float* __restrict__ pre, float* __restrict__ dd, int lddd,
+                                                      float* __restrict__ dpre, int B, int F, const long* __restrict__ row_code,
+                                                      long code, int accumulate_dd) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * F) return;
+  const int b = idx / F, f = idx % F;
+  float gd = 0.f, gp = 0.f;
+  if (!(row_code && row_code[b] == code)) {
+    const float g = 1.f / (1.f + __expf(-pre[idx])), g_y = dy[idx];
+    gd = g_y * g;
+    gp = g_y * d[(long)b * ldd + f] * g * (1.f - g);
+  }
+  float* o = dd + (long)b * lddd + f;
+  *o = accumulate_dd ? *o + gd : gd;
+  dpre[idx] = gp;
 }
 
 __global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int D, float scale) {
@@ -321,15 +353,30 @@ extern "C" int missm_small_linear_fwd(const float* x, const float* w, const floa
 
 extern "C" int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
                                       float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
-                                      int accumulate_dx, void* stream) {
+                                      int accumulate_dx, int accumulate_dw, void* stream) {
   MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && lddy >= O, "small_linear_bwd: bad shape");
   MISSM_CHECK_ARG(!relu_y || lddy == O, "small_linear_bwd: the relu mask is dense, dy must be too");
   if (dx) {
     if (!accumulate_dx) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * I, S_(stream)) != hipSuccess) { missm_set_error("small_linear_bwd: memset failed"); return MISSM_ERR_LAUNCH; } }
     hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, accumulate_dx);
   }
-  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub);
+  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, accumulate_dw);
   return missm_check_launch("small_linear_bwd");
+}
+
+extern "C" int missm_gate_fwd(const float* d, int ldd, const float* pre, float* y, int B, int F, const long* row_code, long code,
+                              int accumulate, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && F > 0 && ldd >= F, "gate_fwd: bad shape");
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(((long)B * F + 255) / 256), dim3(256), 0, S_(stream), d, ldd, pre, y, B, F, row_code, code, accumulate);
+  return missm_check_launch("gate_fwd");
+}
+
+extern "C" int missm_gate_bwd(const float* dy, const float* d, int ldd, const float* pre, float* dd, int lddd, float* dpre, int B, int F,
+                              const long* row_code, long code, int accumulate_dd, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && F > 0 && ldd >= F && lddd >= F, "gate_bwd: bad shape");
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(((long)B * F + 255) / 256), dim3(256), 0, S_(stream), dy, d, ldd, pre, dd, lddd, dpre, B, F, row_code,
+                     code, accumulate_dd);
+  return missm_check_launch("gate_bwd");
 }
 
 extern "C" int missm_l2norm_scale_fwd(const float* x, float* y, int B, int D, float scale, void* stream) {

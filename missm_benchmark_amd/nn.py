@@ -145,6 +145,73 @@ def fused_modal_concat(missing_index, codes: Sequence[int], xs, linears: Sequenc
                                  *[l.bias for l in linears], *subs)
 
 
+class _IntraAttentionFn(torch.autograd.Function):
+    """Intra-modality (channel) attention fusion, reference src/model/baseline.py:183-205:
+         d_m = x_m W_m^T + b_m ;  g_m = sigmoid(W2 relu(W1 [d_m | r] + b1) + b2) ;  z = sum_m (missing_m ? 0 : d_m * g_m)
+    with r the learned fusion representation row and W1, W2 shared by the modalities.  Per modality the projection writes
+    d_m straight into the left half of the [d_m | r] row, the gate kernel applies sigmoid, product, missing-row mask and the
+    sum over modalities in one pass; the backward mirrors it and accumulates the shared layers' gradients in the kernels."""
+
+    @staticmethod
+    def forward(ctx, missing, codes, n, rep, w1, b1, w2, b2, *tensors):
+        xs, ws, bs = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        _gpu(xs[0], "intra-attention fusion")
+        xs = tuple(x.contiguous().float() for x in xs)
+        B, F = xs[0].shape[0], ws[0].shape[0]
+        dev = xs[0].device
+        z = torch.empty(B, F, device=dev, dtype=torch.float32)
+        saved = []
+        for i in range(n):
+            c = torch.empty(B, 2 * F, device=dev, dtype=torch.float32)
+            ops.small_linear_fwd(xs[i], ws[i], bs[i], c[:, :F])
+            c[:, F:].copy_(rep.expand(B, F))                      # broadcast copy of the representation row (no arithmetic)
+            h1 = torch.empty(B, w1.shape[0], device=dev, dtype=torch.float32)
+            ops.small_linear_fwd(c, w1, b1, h1, relu=True)
+            pre = torch.empty(B, F, device=dev, dtype=torch.float32)
+            ops.small_linear_fwd(h1, w2, b2, pre)
+            ops.gate_fwd(c[:, :F], pre, z, row_code=missing, code=codes[i], accumulate=i > 0)
+            saved += [c, h1, pre]
+        ctx.save_for_backward(missing, w1, w2, *xs, *ws, *saved)
+        ctx.codes, ctx.n = codes, n
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        n, codes = ctx.n, ctx.codes
+        missing, w1, w2 = ctx.saved_tensors[:3]
+        xs, ws = ctx.saved_tensors[3:3 + n], ctx.saved_tensors[3 + n:3 + 2 * n]
+        saved = ctx.saved_tensors[3 + 2 * n:]
+        dz = dz.contiguous()
+        B, F = dz.shape
+        dev = dz.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        dw1, db1 = torch.empty_like(w1), torch.empty(w1.shape[0], **f32)
+        dw2, db2 = torch.empty_like(w2), torch.empty(w2.shape[0], **f32)
+        drep = torch.zeros(F, **f32)
+        dxs, dws, dbs = [], [], []
+        for i in range(n):
+            c, h1, pre = saved[3 * i:3 * i + 3]
+            dc = torch.empty(B, 2 * F, **f32)
+            dpre, dh1 = torch.empty(B, F, **f32), torch.empty_like(h1)
+            tmp = torch.empty(B, F, **f32)
+            ops.gate_bwd(dz, c[:, :F], pre, tmp, dpre, row_code=missing, code=codes[i])         # tmp = dz * g (masked)
+            ops.small_linear_bwd(dpre, h1, w2, dh1, dw2, db2, accumulate_dw=i > 0)
+            ops.small_linear_bwd(dh1, c, w1, dc, dw1, db1, relu_y=h1, accumulate_dw=i > 0)
+            ops.gate_bwd(dz, c[:, :F], pre, dc[:, :F], dpre, row_code=missing, code=codes[i], accumulate_dd=True)   # + dz * g
+            ops.colsum(dc[:, F:], drep)
+            dx, dw, db = torch.empty_like(xs[i]), torch.empty_like(ws[i]), torch.empty(F, **f32)
+            ops.small_linear_bwd(dc[:, :F], xs[i], ws[i], dx, dw, db)
+            dxs.append(dx); dws.append(dw); dbs.append(db)
+        return (None, None, None, drep.view(1, F), dw1, db1, dw2, db2, *dxs, *dws, *dbs)
+
+
+def fused_intra_attention(missing_index, codes: Sequence[int], xs, linears: Sequence[HipLinear], representation, lin1: HipLinear,
+                          lin2: HipLinear):
+    n = len(xs)
+    return _IntraAttentionFn.apply(missing_index.contiguous(), tuple(int(c) for c in codes), n, representation, lin1.weight, lin1.bias,
+                                   lin2.weight, lin2.bias, *xs, *[l.weight for l in linears], *[l.bias for l in linears])
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

@@ -254,13 +254,26 @@ def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, x_sub=
     return y
 
 
-def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, x_sub=None, accumulate_dx=False):
+def gate_fwd(d, pre, y, *, row_code=None, code=0, accumulate=False):
+    B, F = pre.shape
+    _lib.call("missm_gate_fwd", d.data_ptr(), d.stride(0), pre.data_ptr(), y.data_ptr(), B, F, _p(row_code), int(code), int(accumulate), _s())
+    return y
+
+
+def gate_bwd(dy, d, pre, dd, dpre, *, row_code=None, code=0, accumulate_dd=False):
+    B, F = pre.shape
+    _lib.call("missm_gate_bwd", dy.data_ptr(), d.data_ptr(), d.stride(0), pre.data_ptr(), dd.data_ptr(), dd.stride(0), dpre.data_ptr(), B, F,
+              _p(row_code), int(code), int(accumulate_dd), _s())
+
+
+def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, x_sub=None, accumulate_dx=False,
+                     accumulate_dw=False):
     B, I = x.shape
     O = w.shape[0]
     if dy.shape[1] != O or dy.stride(1) != 1:
         raise _lib.MissmError("small_linear_bwd: bad dy layout")
     _lib.call("missm_small_linear_bwd", dy.data_ptr(), dy.stride(0), x.data_ptr(), w.data_ptr(), _p(relu_y), _p(dx), _p(dw), _p(dbias),
-              B, I, O, _p(row_code), int(code), _p(x_sub), int(accumulate_dx), _s())
+              B, I, O, _p(row_code), int(code), _p(x_sub), int(accumulate_dx), int(accumulate_dw), _s())
 
 
 def l2norm_scale_fwd(x, y, scale):

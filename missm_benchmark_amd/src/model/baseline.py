@@ -2,8 +2,8 @@
 
 ``finetune_model(args, output_dims, encoder_model)`` keeps the reference constructor / attributes / forward:
 ``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
-fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90) and ``'retrieval'``
-(:164-180) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90), ``'retrieval'``
+(:164-180) and ``'intra_attention'`` (:183-205) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
 the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
 state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
 
@@ -98,7 +98,29 @@ class modal_concat_full(_FusionBase):
             missing_index, self._codes(), [batch[m] for m in self.modality_types], [self.modal_proj[m] for m in self.modality_types])))
 
 
-_NOT_YET = ("regression", "intra_attention", "inter_attention", "graph_fusion", "unified_graph",
+class modal_intra_channel_attention(_FusionBase):
+    """Intra-modality attention (reference :183-205): every projected modality is re-weighted channel-wise by a gate computed
+    from it and a learned fusion representation; missing rows are zeroed after the gate; the modalities are summed."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim)
+        F = args.fusion_dim
+        if F % 16:
+            raise ValueError("fusion_dim must be a multiple of 16 (the gate MLP is fusion_dim // 4 wide)")
+        self.fusion_representation = nn.Parameter(torch.randn(1, F))
+        ca = nn.Module()                                     # keeps the reference's nn.Sequential keys: channel_attention.{0,2}.*
+        ca.add_module("0", hnn.HipLinear(2 * F, F // 4, relu=True))
+        ca.add_module("2", hnn.HipLinear(F // 4, F))
+        self.channel_attention = ca
+
+    def forward(self, batch, missing_index):
+        m = self.channel_attention._modules
+        z = hnn.fused_intra_attention(missing_index, self._codes(), [batch[k] for k in self.modality_types],
+                                      [self.modal_proj[k] for k in self.modality_types], self.fusion_representation, m["0"], m["2"])
+        return self.head(self.norm(z))
+
+
+_NOT_YET = ("regression", "inter_attention", "graph_fusion", "unified_graph",
             "dedicated_dnn", "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
 
 
@@ -113,6 +135,8 @@ class finetune_model(nn.Module):
             self.fusion = modal_concat(args, output_dims)
         elif args.fusion_type == "retrieval":
             self.fusion = modal_concat_full(args, output_dims)
+        elif args.fusion_type == "intra_attention":
+            self.fusion = modal_intra_channel_attention(args, output_dims)
         elif args.fusion_type in _NOT_YET:
             raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
         else:

@@ -138,8 +138,9 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
             return data
 
     model = base.finetune_model(args, classes, _Enc()).eval()
-    head_in = fusion_dim if fusion_type == "sum" else fusion_dim * len(modality_types)
-    fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed, head_in=head_in)
+    head_in = fusion_dim if fusion_type in ("sum", "intra_attention") else fusion_dim * len(modality_types)
+    fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed, head_in=head_in,
+                              intra_attention=fusion_type == "intra_attention")
     model.fusion.load_state_dict(fp, strict=False)        # (the concat head also carries statistics_<modal> buffers)
     g = _gen(seed + 1)
     stats = None
@@ -162,8 +163,12 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
     torch.save(fix, os.path.join(OUT, name + ".pt"))
     with torch.no_grad():
         e0 = {m: e.detach() for m, e in emb.items()}
-        lo = O.fusion_sum(e0, missing, fp, modality_types) if fusion_type == "sum" else \
-            O.fusion_concat(e0, missing, fp, modality_types, stats, mask=fusion_type == "concat")
+        if fusion_type == "sum":
+            lo = O.fusion_sum(e0, missing, fp, modality_types)
+        elif fusion_type == "intra_attention":
+            lo = O.fusion_intra_attention(e0, missing, fp, modality_types)
+        else:
+            lo = O.fusion_concat(e0, missing, fp, modality_types, stats, mask=fusion_type == "concat")
     print(f"{name}: ref-vs-oracle logits {float((lo - logits).abs().max()):.2e}")
 
 
@@ -250,6 +255,8 @@ def main():
                    fusion_type="concat")
     run(fusion_fixture, "fusion_retrieval", ["language", "video", "image"], batch=9, feature_dims=48, fusion_dim=32, classes=4, seed=22,
                    fusion_type="retrieval")
+    run(fusion_fixture, "fusion_intra_attention", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
+        seed=23, fusion_type="intra_attention")
     run(bundle_fixture, "bundle", seed=12)
     run(missing_fixture, "missing_index")
     # BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224 (weights by recipe, outputs stored)

@@ -310,6 +310,24 @@ def fusion_concat(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, mod
     return head_forward(z, fp)
 
 
+def fusion_intra_attention(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                           codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_intra_channel_attention.forward`` src/model/baseline.py:183-205: per modality d = Linear(x);
+    gate = sigmoid(Linear(relu(Linear([d | fusion_representation])))); d * gate, missing rows zeroed; sum; LayerNorm; Head."""
+    z = None
+    rep = fp["fusion_representation"]
+    for m in modality_types:
+        d = F.linear(emb[m], fp[f"modal_proj.{m}.weight"], fp[f"modal_proj.{m}.bias"])
+        c = torch.cat([d, rep.expand(d.shape[0], -1)], dim=-1)
+        h = F.relu(F.linear(c, fp["channel_attention.0.weight"], fp["channel_attention.0.bias"]))
+        g = torch.sigmoid(F.linear(h, fp["channel_attention.2.weight"], fp["channel_attention.2.bias"]))
+        y = d * g
+        y = torch.where((missing_index == codes[m])[:, None], torch.zeros_like(y), y)
+        z = y if z is None else z + y
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
@@ -407,7 +425,7 @@ def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
 
 
 def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
-                       seed: int, head_in: Optional[int] = None) -> Params:
+                       seed: int, head_in: Optional[int] = None, intra_attention: bool = False) -> Params:
     """Seeded init for ``modal_sum`` / ``modal_concat`` / ``modal_concat_full`` + ``Head`` (src/model/baseline.py:27-50,66-71)
     parameter names; head_in = width of the fused row (fusion_dim for sum, fusion_dim * M for the concat heads)."""
     gen = torch.Generator().manual_seed(seed)
@@ -422,6 +440,12 @@ def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_
     fp["head.head.0.bias"] = _normal((fusion_dim,), 0.02, gen)
     fp["head.head.3.weight"] = _normal((num_classes, fusion_dim), fusion_dim ** -0.5, gen)
     fp["head.head.3.bias"] = _normal((num_classes,), 0.02, gen)
+    if intra_attention:                          # modal_intra_channel_attention (:190-196)
+        fp["fusion_representation"] = _normal((1, fusion_dim), 1.0, gen)
+        fp["channel_attention.0.weight"] = _normal((fusion_dim // 4, 2 * fusion_dim), (2 * fusion_dim) ** -0.5, gen)
+        fp["channel_attention.0.bias"] = _normal((fusion_dim // 4,), 0.02, gen)
+        fp["channel_attention.2.weight"] = _normal((fusion_dim, fusion_dim // 4), (fusion_dim // 4) ** -0.5, gen)
+        fp["channel_attention.2.bias"] = _normal((fusion_dim,), 0.02, gen)
     return fp
 
 

@@ -112,13 +112,16 @@ def test_fusion_sum_and_loss():
         assert (fp[k].grad - g).abs().max() < TOL, k
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention"])
 def test_fusion_concat_heads(name):
     """modal_concat (imputation statistics set through set_statistics) and modal_concat_full against the reference's outputs"""
     fix = load_golden(name)
     fp = {k: v.clone().requires_grad_(True) for k, v in fix["params"].items()}
     emb = {m: e.clone().requires_grad_(True) for m, e in fix["emb"].items()}
-    logits = O.fusion_concat(emb, fix["missing_index"], fp, fix["modality_types"], fix["statistics"], mask=fix["fusion_type"] == "concat")
+    if fix["fusion_type"] == "intra_attention":
+        logits = O.fusion_intra_attention(emb, fix["missing_index"], fp, fix["modality_types"])
+    else:
+        logits = O.fusion_concat(emb, fix["missing_index"], fp, fix["modality_types"], fix["statistics"], mask=fix["fusion_type"] == "concat")
     assert (logits - fix["logits"]).abs().max() < TOL
     loss = O.cross_entropy(logits, fix["labels"])
     assert abs(float(loss.detach()) - float(fix["loss"])) < TOL
