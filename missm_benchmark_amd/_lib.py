@@ -59,6 +59,10 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch ships its own copy of the HIP runtime (torch/lib/libamdhip64.so); this library links the same SONAME.  torch must be
+    # imported first so that both resolve to ONE runtime instance: loaded the other way round, /opt/rocm's copy serves this
+    # library, torch's copy serves torch, and the second runtime to touch the device reports "no ROCm-capable device".
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise MissmError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                          "(missm_benchmark_amd/csrc/build.sh). There is no fallback path.")
