@@ -2,6 +2,7 @@
 
 Tolerances: fp32 instantiation 2e-5 relative to the output scale (exact-f32 MFMA, different summation order);
 bf16 instantiation 2e-2 (8-bit mantissa operands, fp32 accumulation)."""
+import os
 import math
 
 import pytest
@@ -490,3 +491,20 @@ def test_adam_matches_torch(ops):
         opt.step()
         ops.adam_step(p, dev(g * 4.0), m, v, step, 1e-3, weight_decay=0.01, grad_scale=0.25)
     assert rel(p, ref.detach()) < 1e-6
+
+
+def test_library_loaded_before_torch_still_sees_the_gpu():
+    """A process that touches the binding before importing torch (as `__graft_entry__.build()` followed by `smoke()` does) must end
+    up with ONE HIP runtime: torch ships its own libamdhip64 and the library links the same SONAME."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from missm_benchmark_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "import torch\n"
+            "from missm_benchmark_amd import ops\n"
+            "x = torch.randn(64, 64, device='cuda'); y = torch.empty(64, 64, device='cuda'); m = torch.empty(64, device='cuda'); r = torch.empty(64, device='cuda')\n"
+            "ops.layernorm_fwd(x, torch.ones(64, device='cuda'), torch.zeros(64, device='cuda'), y, m, r, 64, 64, 1e-5)\n"
+            "torch.cuda.synchronize(); print('ok', float(y.abs().mean()))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
