@@ -4,7 +4,7 @@ both counters are in KiB.  Usage: pmc_traffic.py <fetch counter_collection.csv> 
 import json, sys
 import pandas as pd
 
-FAMILIES = (("gemm", ("gemm_kernel", "splitk_reduce")), ("ln", ("ln_fwd", "ln_bwd")), ("attn", ("attn_",)), ("adam", ("adam_kernel",)))
+FAMILIES = (("gemm", ("gemm_kernel", "splitk_reduce")), ("ln", ("ln_fwd", "ln_bwd")), ("attn", ("attn_",)), ("adam", ("adam_kernel", "adam_cast_batched")))
 
 
 def family(name):
