@@ -92,13 +92,17 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int I, int O,
                                                               int ldy, int relu, const long* __restrict__ row_code, long code,
-                                                              const float* __restrict__ x_sub, int accumulate) {
+                                                              const float* __restrict__ x_sub, int select, int accumulate) {
   const int lane = threadIdx.x & 63;
   const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= (long)B * O) return;
   const int b = e / O, o = e % O;
   float acc = 0.f;
-  const bool masked = row_code && row_code[b] == code;
+  bool masked = row_code && row_code[b] == code;
+  if (select) {                 // select mode: ONLY the rows carrying the code are computed and written (dedicated networks)
+    if (!masked) return;
+    masked = false;
+  }
   if (!masked || x_sub) {       // a masked row is either zeroed or computed from the substitute input row
     const float* xr = masked ? x_sub : x + (long)b * I;
     const float* wr = w + (long)o * I;
@@ -114,8 +118,9 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __re
 }
 
 // effective dy (masked by row code and by relu) helper
-__device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* relu_y, const long* row_code, long code, int b, int o, int O) {
-  if (row_code && row_code[b] == code) return 0.f;
+__device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* relu_y, const long* row_code, long code, int b, int o, int O,
+                                        int select = 0) {
+  if (row_code && ((row_code[b] == code) != (select != 0))) return 0.f;   // masked rows (or, in select mode, all the others)
   const float g = dy[(long)b * lddy + o];
   if (relu_y && relu_y[(long)b * O + o] <= 0.f) return 0.f;
   return g;
@@ -125,13 +130,13 @@ __device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* 
 // partial sums added atomically into a zeroed / accumulated dx) so the launch fills the chip instead of 96 workgroups
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
-                                                             int lddy, const long* __restrict__ row_code, long code, int accumulate) {
+                                                             int lddy, const long* __restrict__ row_code, long code, int select, int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * I) return;
   const int b = idx / I, i = idx % I;
   const int o0 = blockIdx.y * 32, o1 = min(O, o0 + 32);
   float acc = 0.f;
-  for (int o = o0; o < o1; ++o) acc += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O) * w[(long)o * I + i];
+  for (int o = o0; o < o1; ++o) acc += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
   atomicAdd(dx + idx, acc);
 }
 
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
                                                              const float* __restrict__ relu_y, float* __restrict__ dw,
                                                              float* __restrict__ dbias, int B, int I, int O, int lddy,
                                                              const long* __restrict__ row_code, long code, const float* __restrict__ x_sub,
-                                                             int accumulate) {
+                                                             int select, int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)O * I) return;
   const int o = idx / I, i = idx % I;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
   for (int b = 0; b < B; ++b) {
     // with a substitute row the masked samples still feed the weights (their input is x_sub), only dx is cut
     const bool subst = x_sub && row_code && row_code[b] == code;
-    const float g = eff_dy(dy, lddy, relu_y, subst ? nullptr : row_code, code, b, o, O);
+    const float g = eff_dy(dy, lddy, relu_y, subst ? nullptr : row_code, code, b, o, O, select);
     acc += g * (subst ? x_sub[i] : x[(long)b * I + i]);
     accb += g;
   }
@@ -343,25 +348,40 @@ extern "C" int missm_argmax_rows(const long* ids, int* out, int B, int S, void* 
 }
 
 extern "C" int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int ldy, int relu,
-                                      const long* row_code, long code, const float* x_sub, int accumulate, void* stream) {
+                                      const long* row_code, long code, const float* x_sub, int select, int accumulate, void* stream) {
   MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && I % 4 == 0 && ldy >= O, "small_linear_fwd: bad shape (I must be a multiple of 4, ldy >= O)");
   MISSM_CHECK_ARG(!x_sub || row_code, "small_linear_fwd: a substitute row needs row codes");
+  MISSM_CHECK_ARG(!select || (row_code && !x_sub), "small_linear_fwd: select mode needs row codes and no substitute row");
   const long e = (long)B * O;
-  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, ldy, relu, row_code, code, x_sub, accumulate);
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, ldy, relu, row_code, code, x_sub, select, accumulate);
   return missm_check_launch("small_linear_fwd");
 }
 
 extern "C" int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
                                       float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
-                                      int accumulate_dx, int accumulate_dw, void* stream) {
+                                      int select, int accumulate_dx, int accumulate_dw, void* stream) {
   MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && lddy >= O, "small_linear_bwd: bad shape");
   MISSM_CHECK_ARG(!relu_y || lddy == O, "small_linear_bwd: the relu mask is dense, dy must be too");
   if (dx) {
     if (!accumulate_dx) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * I, S_(stream)) != hipSuccess) { missm_set_error("small_linear_bwd: memset failed"); return MISSM_ERR_LAUNCH; } }
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, accumulate_dx);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, accumulate_dx);
   }
-  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, accumulate_dw);
+  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, select, accumulate_dw);
   return missm_check_launch("small_linear_bwd");
+}
+
+// dst[b, 0:W] += src[b, 0:W] for two row-strided blocks (gradient slices of a concatenated feature row meeting again)
+__global__ __launch_bounds__(256) void add_block_kernel(float* __restrict__ dst, int lddst, const float* __restrict__ src, int ldsrc, int B, int W) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * W) return;
+  const int b = idx / W, c = idx % W;
+  dst[(long)b * lddst + c] += src[(long)b * ldsrc + c];
+}
+
+extern "C" int missm_add_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && W > 0 && lddst >= W && ldsrc >= W, "add_block: bad shape");
+  hipLaunchKernelGGL(add_block_kernel, dim3(((long)B * W + 255) / 256), dim3(256), 0, S_(stream), dst, lddst, src, ldsrc, B, W);
+  return missm_check_launch("add_block");
 }
 
 extern "C" int missm_gate_fwd(const float* d, int ldd, const float* pre, float* y, int B, int F, const long* row_code, long code,

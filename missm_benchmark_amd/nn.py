@@ -212,6 +212,59 @@ def fused_intra_attention(missing_index, codes: Sequence[int], xs, linears: Sequ
                                    lin2.weight, lin2.bias, *xs, *[l.weight for l in linears], *[l.bias for l in linears])
 
 
+class _DedicatedDnnFn(torch.autograd.Function):
+    """Dedicated-network fusion, reference src/model/baseline.py:333-353: z = full(cat_m x_m); the rows whose modality m is
+    missing are overwritten by dedicated_m(cat of the OTHER modalities).  `sel[b]` = 0 (full network) or m + 1.  Each network
+    runs in select mode on its own rows only (forward and backward); its input gradient is dense over its own concatenation,
+    and the per-modality slices of the networks' input gradients are summed with a strided block add."""
+
+    @staticmethod
+    def forward(ctx, sel, n, w_full, b_full, *tensors):
+        xs, wds, bds = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        _gpu(xs[0], "dedicated-network fusion")
+        xs = tuple(x.contiguous().float() for x in xs)
+        B, C = xs[0].shape
+        F = w_full.shape[0]
+        feat = torch.cat(xs, dim=-1)                                           # copies (no arithmetic)
+        wo = [torch.cat([xs[j] for j in range(n) if j != i], dim=-1) for i in range(n)]
+        z = torch.zeros(B, F, device=feat.device, dtype=torch.float32)
+        ops.small_linear_fwd(feat, w_full, b_full, z, row_code=sel, code=0, select=True)
+        for i in range(n):
+            ops.small_linear_fwd(wo[i], wds[i], bds[i], z, row_code=sel, code=i + 1, select=True)
+        ctx.save_for_backward(sel, feat, w_full, *wo, *wds)
+        ctx.n, ctx.C = n, C
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        n, C = ctx.n, ctx.C
+        sel, feat, w_full = ctx.saved_tensors[:3]
+        wo, wds = ctx.saved_tensors[3:3 + n], ctx.saved_tensors[3 + n:]
+        dz = dz.contiguous()
+        f32 = dict(device=dz.device, dtype=torch.float32)
+        dfeat = torch.empty_like(feat)
+        dwf, dbf = torch.empty_like(w_full), torch.empty(w_full.shape[0], **f32)
+        ops.small_linear_bwd(dz, feat, w_full, dfeat, dwf, dbf, row_code=sel, code=0, select=True)
+        dwds, dbds = [], []
+        for i in range(n):
+            d_i = torch.empty_like(wo[i])
+            dw, db = torch.empty_like(wds[i]), torch.empty(wds[i].shape[0], **f32)
+            ops.small_linear_bwd(dz, wo[i], wds[i], d_i, dw, db, row_code=sel, code=i + 1, select=True)
+            if i > 0:                                    # modalities 0..i-1 sit at the same columns in both layouts
+                ops.add_block(dfeat[:, :i * C], d_i[:, :i * C])
+            if i < n - 1:                                # modalities i+1..n-1 are shifted left by one block in wo[i]
+                ops.add_block(dfeat[:, (i + 1) * C:], d_i[:, i * C:])
+            dwds.append(dw); dbds.append(db)
+        dxs = [dfeat[:, m * C:(m + 1) * C].contiguous() for m in range(n)]
+        return (None, None, dwf, dbf, *dxs, *dwds, *dbds)
+
+
+def fused_dedicated_dnn(selector, xs, full: HipLinear, dedicated: Sequence[HipLinear]):
+    n = len(xs)
+    return _DedicatedDnnFn.apply(selector.contiguous(), n, full.weight, full.bias, *xs, *[l.weight for l in dedicated],
+                                 *[l.bias for l in dedicated])
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

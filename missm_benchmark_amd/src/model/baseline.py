@@ -3,7 +3,7 @@
 ``finetune_model(args, output_dims, encoder_model)`` keeps the reference constructor / attributes / forward:
 ``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
 fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90), ``'retrieval'``
-(:164-180) and ``'intra_attention'`` (:183-205) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+(:164-180), ``'intra_attention'`` (:183-205) and ``'dedicated_dnn'`` (:333-353) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
 the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
 state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
 
@@ -120,8 +120,34 @@ class modal_intra_channel_attention(_FusionBase):
         return self.head(self.norm(z))
 
 
+class modal_dedicated_dnn(nn.Module):
+    """Dedicated training (reference :333-353): one network over all modalities and one per missing-modality case over the
+    remaining ones; every sample is routed to the network of its missing code."""
+
+    def __init__(self, args, output_dims):
+        super().__init__()
+        self.modality_types = list(args.modality_types)
+        M = len(self.modality_types)
+        if M < 2:
+            raise ValueError("dedicated_dnn needs at least two modalities")
+        nets = {m: hnn.HipLinear(args.feature_dims * (M - 1), args.fusion_dim) for m in self.modality_types}
+        nets["full"] = hnn.HipLinear(args.feature_dims * M, args.fusion_dim)
+        self.dedicated_dnn = nn.ModuleDict(nets)
+        self.norm = hnn.HipLayerNorm(args.fusion_dim)
+        self.head = Head(args, args.fusion_dim, output_dims)
+
+    def forward(self, batch, missing_index):
+        # routing table (index bookkeeping on int64 codes, like the reference's boolean masks): 0 = full, m + 1 = modality m missing
+        sel = torch.zeros_like(missing_index)
+        for i, m in enumerate(self.modality_types):
+            sel = torch.where(missing_index == missing_type_index[m], torch.full_like(sel, i + 1), sel)
+        z = hnn.fused_dedicated_dnn(sel, [batch[m] for m in self.modality_types], self.dedicated_dnn["full"],
+                                    [self.dedicated_dnn[m] for m in self.modality_types])
+        return self.head(self.norm(z))
+
+
 _NOT_YET = ("regression", "inter_attention", "graph_fusion", "unified_graph",
-            "dedicated_dnn", "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
+            "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
 
 
 class finetune_model(nn.Module):
@@ -137,6 +163,8 @@ class finetune_model(nn.Module):
             self.fusion = modal_concat_full(args, output_dims)
         elif args.fusion_type == "intra_attention":
             self.fusion = modal_intra_channel_attention(args, output_dims)
+        elif args.fusion_type == "dedicated_dnn":
+            self.fusion = modal_dedicated_dnn(args, output_dims)
         elif args.fusion_type in _NOT_YET:
             raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
         else:

@@ -328,6 +328,20 @@ def fusion_intra_attention(emb: Dict[str, Tensor], missing_index: Tensor, fp: Pa
     return head_forward(z, fp)
 
 
+def fusion_dedicated_dnn(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                         codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_dedicated_dnn.forward`` src/model/baseline.py:345-353: full network on the concatenated embeddings; rows whose
+    modality i is missing are overwritten by dedicated_i over the concatenation without block i; LayerNorm; Head."""
+    feats = [emb[m] for m in modality_types]
+    z = F.linear(torch.cat(feats, dim=-1), fp["dedicated_dnn.full.weight"], fp["dedicated_dnn.full.bias"])
+    for i, m in enumerate(modality_types):
+        wo = torch.cat(feats[:i] + feats[i + 1:], dim=-1)
+        zi = F.linear(wo, fp[f"dedicated_dnn.{m}.weight"], fp[f"dedicated_dnn.{m}.bias"])
+        z = torch.where((missing_index == codes[m])[:, None], zi, z)
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
@@ -425,15 +439,23 @@ def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
 
 
 def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
-                       seed: int, head_in: Optional[int] = None, intra_attention: bool = False) -> Params:
+                       seed: int, head_in: Optional[int] = None, intra_attention: bool = False, dedicated: bool = False) -> Params:
     """Seeded init for ``modal_sum`` / ``modal_concat`` / ``modal_concat_full`` + ``Head`` (src/model/baseline.py:27-50,66-71)
     parameter names; head_in = width of the fused row (fusion_dim for sum, fusion_dim * M for the concat heads)."""
     gen = torch.Generator().manual_seed(seed)
     head_in = fusion_dim if head_in is None else head_in
     fp: Params = {}
-    for m in modality_types:
-        fp[f"modal_proj.{m}.weight"] = _normal((fusion_dim, feature_dims), feature_dims ** -0.5, gen)
-        fp[f"modal_proj.{m}.bias"] = _normal((fusion_dim,), 0.02, gen)
+    M = len(modality_types)
+    if dedicated:                                # modal_dedicated_dnn (:339-343): no modal_proj
+        for m in modality_types:
+            fp[f"dedicated_dnn.{m}.weight"] = _normal((fusion_dim, feature_dims * (M - 1)), (feature_dims * (M - 1)) ** -0.5, gen)
+            fp[f"dedicated_dnn.{m}.bias"] = _normal((fusion_dim,), 0.02, gen)
+        fp["dedicated_dnn.full.weight"] = _normal((fusion_dim, feature_dims * M), (feature_dims * M) ** -0.5, gen)
+        fp["dedicated_dnn.full.bias"] = _normal((fusion_dim,), 0.02, gen)
+    else:
+        for m in modality_types:
+            fp[f"modal_proj.{m}.weight"] = _normal((fusion_dim, feature_dims), feature_dims ** -0.5, gen)
+            fp[f"modal_proj.{m}.bias"] = _normal((fusion_dim,), 0.02, gen)
     fp["norm.weight"] = 1.0 + _normal((head_in,), 0.02, gen)
     fp["norm.bias"] = _normal((head_in,), 0.02, gen)
     fp["head.head.0.weight"] = _normal((fusion_dim, head_in), head_in ** -0.5, gen)

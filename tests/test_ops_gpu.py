@@ -436,6 +436,19 @@ def test_small_linear_l2norm_ce_dropout(ops):
     refs.backward(dwide[:, O:2 * O])
     ops.small_linear_bwd(dev(dwide)[:, O:2 * O], dev(x), dev(w), dx, dw, db, row_code=dev(code), code=2, x_sub=dev(sub_row))
     assert rel(dx, xr.grad) < 1e-5 and rel(dw, wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    # select mode: only the rows carrying the code are computed / written / differentiated (dedicated networks); block add
+    ysel = torch.full((B, O), 5.0, device="cuda")
+    ops.small_linear_fwd(dev(x), dev(w), dev(b), ysel, row_code=dev(code), code=3, select=True)
+    hit = (code == 3)[:, None]
+    assert rel(ysel, torch.where(hit, F.linear(x, w, b), torch.full((B, O), 5.0))) < 1e-5
+    xr.grad = wr.grad = br.grad = None
+    torch.where(hit, F.linear(xr, wr, br), torch.zeros(B, O)).backward(dy)
+    ops.small_linear_bwd(dev(dy), dev(x), dev(w), dx, dw, db, row_code=dev(code), code=3, select=True)
+    assert rel(dx, xr.grad) < 1e-5 and rel(dw, wr.grad) < 1e-5 and rel(db, br.grad) < 1e-5
+    blk = dev(rnd(B, 3 * O, seed=8))
+    want = blk.clone(); want[:, O:2 * O] += dev(dy)
+    ops.add_block(blk[:, O:2 * O], dev(dy))
+    assert torch.equal(blk, want)
     # relu variant
     yr = torch.empty(B, O, device="cuda")
     ops.small_linear_fwd(dev(x), dev(w), dev(b), yr, relu=True)

@@ -212,19 +212,20 @@ def test_fusion_sum_and_bundle_vs_reference_fixture(pkg, dtype, tol):
         assert rel(hnn.l2norm_scale(e, scale), ref) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn"])
 def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     """fusion_type 'concat' (zero / mean / median imputation through set_statistics, test.py:112-115) and 'retrieval':
     projections written straight into their slice of the concatenated row; logits, loss and every gradient against the
     fixture captured from the reference."""
     fix = load_golden(name)
     mt = fix["modality_types"]
-    fd = fix["params"]["modal_proj." + mt[0] + ".weight"].shape
-    args = types.SimpleNamespace(modality_types=mt, feature_dims=fd[1], fusion_dim=fd[0], dropout_prob=0.0, fusion_type=fix["fusion_type"])
+    fdim, cdim = fix["params"]["head.head.3.weight"].shape[1], next(iter(fix["emb"].values())).shape[1]
+    args = types.SimpleNamespace(modality_types=mt, feature_dims=cdim, fusion_dim=fdim, dropout_prob=0.0, fusion_type=fix["fusion_type"])
     C = fix["logits"].shape[1]
     model = pkg.base.finetune_model(args, C, torch.nn.Identity())
     assert type(model.fusion).__name__ == {"concat": "modal_concat", "retrieval": "modal_concat_full",
-                                           "intra_attention": "modal_intra_channel_attention"}[fix["fusion_type"]]
+                                           "intra_attention": "modal_intra_channel_attention",
+                                           "dedicated_dnn": "modal_dedicated_dnn"}[fix["fusion_type"]]
     missing, unexpected = model.fusion.load_state_dict(fix["params"], strict=False)
     assert not unexpected and all(k.startswith("statistics_") for k in missing)
     model = model.cuda()
