@@ -135,15 +135,17 @@ int missm_argmax_rows(const long* ids, int* out, int B, int S, void* stream);
  * is given, are computed from that row instead of x[b] (zero / mean / median imputation, src/model/baseline.py:80-82);
  * select != 0 inverts the role of the code: ONLY rows with row_code[b] == code are computed and written, the others are left
  * untouched (a dedicated network overwriting the rows of its missing-modality case, src/model/baseline.py:349-351);
+ * alpha scales (x W^T + bias) before the ReLU (the mean over source modalities of the cross-modal regressors, :139-141);
  * accumulate: y += (sum over modalities). */
 int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int ldy, int relu,
-                           const long* row_code, long code, const float* x_sub, int select, int accumulate, void* stream);
+                           const long* row_code, long code, const float* x_sub, int select, float alpha, int accumulate,
+                           void* stream);
 /* dx[b,i] (= or +=), dw[o,i] (=), dbias[o] (=) for the layer above; dy (row stride lddy) is masked by row_code/code and,
  * when relu_y is given, by relu_y > 0.  With x_sub the masked rows still feed dw / dbias (their input was x_sub); only
  * their dx is zero.  accumulate_dw: dw / dbias += (a layer applied to several modalities). */
 int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
                            float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
-                           int select, int accumulate_dx, int accumulate_dw, void* stream);
+                           int select, float alpha, int accumulate_dx, int accumulate_dw, void* stream);
 /* dst[b, 0:W] += src[b, 0:W] with row strides lddst / ldsrc (gradient slices of a concatenated feature row meeting again). */
 int missm_add_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, void* stream);
 /* Channel-attention gate of the intra-modality attention head (src/model/baseline.py:198-201):

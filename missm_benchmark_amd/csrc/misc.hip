@@ -92,7 +92,7 @@ __global__ __launch_bounds__(256) void cast_rows_kernel(const float* __restrict_
 __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ bias, float* __restrict__ y, int B, int I, int O,
                                                               int ldy, int relu, const long* __restrict__ row_code, long code,
-                                                              const float* __restrict__ x_sub, int select, int accumulate) {
+                                                              const float* __restrict__ x_sub, int select, float alpha, int accumulate) {
   const int lane = threadIdx.x & 63;
   const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (e >= (long)B * O) return;
@@ -112,6 +112,7 @@ __global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float* __re
     }
     acc = wave_sum(acc);
     if (bias) acc += bias[o];
+    acc *= alpha;
     if (relu) acc = fmaxf(acc, 0.f);
   }
   if (lane == 0) { float* yp = y + (long)b * ldy + o; *yp = accumulate ? *yp + acc : acc; }
@@ -130,14 +131,15 @@ __device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* 
 // partial sums added atomically into a zeroed / accumulated dx) so the launch fills the chip instead of 96 workgroups
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
-                                                             int lddy, const long* __restrict__ row_code, long code, int select, int accumulate) {
+                                                             int lddy, const long* __restrict__ row_code, long code, int select, float alpha,
+                                                             int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * I) return;
   const int b = idx / I, i = idx % I;
   const int o0 = blockIdx.y * 32, o1 = min(O, o0 + 32);
   float acc = 0.f;
   for (int o = o0; o < o1; ++o) acc += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
-  atomicAdd(dx + idx, acc);
+  atomicAdd(dx + idx, acc * alpha);
 }
 
 // dw[o, i] = sum_b dyeff[b, o] x[b, i] ; dbias[o] = sum_b dyeff[b, o]
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
                                                              const float* __restrict__ relu_y, float* __restrict__ dw,
                                                              float* __restrict__ dbias, int B, int I, int O, int lddy,
                                                              const long* __restrict__ row_code, long code, const float* __restrict__ x_sub,
-                                                             int select, int accumulate) {
+                                                             int select, float alpha, int accumulate) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)O * I) return;
   const int o = idx / I, i = idx % I;
@@ -157,6 +159,7 @@ __global__ __launch_bounds__(256) void small_linear_dw_kernel(const float* __res
     acc += g * (subst ? x_sub[i] : x[(long)b * I + i]);
     accb += g;
   }
+  acc *= alpha; accb *= alpha;
   dw[idx] = accumulate ? dw[idx] + acc : acc;          // accumulate: a layer shared by several modalities (channel attention)
   if (dbias && i == 0) dbias[o] = accumulate ? dbias[o] + accb : accb;
 }
@@ -348,25 +351,27 @@ extern "C" int missm_argmax_rows(const long* ids, int* out, int B, int S, void* 
 }
 
 extern "C" int missm_small_linear_fwd(const float* x, const float* w, const float* bias, float* y, int B, int I, int O, int ldy, int relu,
-                                      const long* row_code, long code, const float* x_sub, int select, int accumulate, void* stream) {
+                                      const long* row_code, long code, const float* x_sub, int select, float alpha, int accumulate,
+                                      void* stream) {
   MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && I % 4 == 0 && ldy >= O, "small_linear_fwd: bad shape (I must be a multiple of 4, ldy >= O)");
   MISSM_CHECK_ARG(!x_sub || row_code, "small_linear_fwd: a substitute row needs row codes");
   MISSM_CHECK_ARG(!select || (row_code && !x_sub), "small_linear_fwd: select mode needs row codes and no substitute row");
   const long e = (long)B * O;
-  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, ldy, relu, row_code, code, x_sub, select, accumulate);
+  hipLaunchKernelGGL(small_linear_fwd_kernel, dim3((e + 3) / 4), dim3(256), 0, S_(stream), x, w, bias, y, B, I, O, ldy, relu, row_code, code, x_sub, select, alpha, accumulate);
   return missm_check_launch("small_linear_fwd");
 }
 
 extern "C" int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const float* w, const float* relu_y, float* dx, float* dw,
                                       float* dbias, int B, int I, int O, const long* row_code, long code, const float* x_sub,
-                                      int select, int accumulate_dx, int accumulate_dw, void* stream) {
+                                      int select, float alpha, int accumulate_dx, int accumulate_dw, void* stream) {
   MISSM_CHECK_ARG(B > 0 && I > 0 && O > 0 && lddy >= O, "small_linear_bwd: bad shape");
   MISSM_CHECK_ARG(!relu_y || lddy == O, "small_linear_bwd: the relu mask is dense, dy must be too");
+  MISSM_CHECK_ARG(!relu_y || alpha == 1.0f, "small_linear_bwd: alpha with a fused ReLU is not supported");
   if (dx) {
     if (!accumulate_dx) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * I, S_(stream)) != hipSuccess) { missm_set_error("small_linear_bwd: memset failed"); return MISSM_ERR_LAUNCH; } }
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, accumulate_dx);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, alpha, accumulate_dx);
   }
-  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, select, accumulate_dw);
+  if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, select, alpha, accumulate_dw);
   return missm_check_launch("small_linear_bwd");
 }
 

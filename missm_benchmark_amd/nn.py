@@ -265,6 +265,74 @@ def fused_dedicated_dnn(selector, xs, full: HipLinear, dedicated: Sequence[HipLi
                                  *[l.bias for l in dedicated])
 
 
+class _RegressionConcatFn(torch.autograd.Function):
+    """Direct-to-task representation generation, reference src/model/baseline.py:93-161: every modality is projected; where
+    modality t is missing its projection is replaced by the mean of the cross-modal regressors reg_{s->t}(x_s) over the other
+    modalities s (one missing code per sample, so all of them are present there); the M blocks are concatenated.
+    Block t of the output row is written by proj_t with the missing rows zeroed, then the regressors add alpha = 1/(M-1) of
+    their prediction to exactly those rows (select mode).  regs[t][s] is the regressor s -> t (None on the diagonal)."""
+
+    @staticmethod
+    def forward(ctx, missing, codes, n, *tensors):
+        xs, wp, bp = tensors[:n], tensors[n:2 * n], tensors[2 * n:3 * n]
+        rw, rb = tensors[3 * n:3 * n + n * n], tensors[3 * n + n * n:]
+        _gpu(xs[0], "regression fusion")
+        xs = tuple(x.contiguous().float() for x in xs)
+        B, F = xs[0].shape[0], wp[0].shape[0]
+        z = torch.empty(B, n * F, device=xs[0].device, dtype=torch.float32)
+        alpha = 1.0 / (n - 1)
+        for t in range(n):
+            zt = z[:, t * F:(t + 1) * F]
+            ops.small_linear_fwd(xs[t], wp[t], bp[t], zt, row_code=missing, code=codes[t])
+            for s in range(n):
+                if s != t:
+                    ops.small_linear_fwd(xs[s], rw[t * n + s], rb[t * n + s], zt, row_code=missing, code=codes[t], select=True,
+                                         alpha=alpha, accumulate=True)
+        ctx.save_for_backward(missing, *xs, *wp, *[w for w in rw if w is not None])
+        ctx.codes, ctx.n = codes, n
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        n, codes = ctx.n, ctx.codes
+        missing = ctx.saved_tensors[0]
+        xs, wp = ctx.saved_tensors[1:1 + n], ctx.saved_tensors[1 + n:1 + 2 * n]
+        it = iter(ctx.saved_tensors[1 + 2 * n:])
+        rw = [None if (i // n) == (i % n) else next(it) for i in range(n * n)]
+        dz = dz.contiguous()
+        F = wp[0].shape[0]
+        f32 = dict(device=dz.device, dtype=torch.float32)
+        alpha = 1.0 / (n - 1)
+        dxs = [torch.empty_like(x) for x in xs]
+        touched = [False] * n
+        dwp, dbp, drw, drb = [], [], [None] * (n * n), [None] * (n * n)
+        for t in range(n):
+            dzt = dz[:, t * F:(t + 1) * F]
+            dw, db = torch.empty_like(wp[t]), torch.empty(F, **f32)
+            ops.small_linear_bwd(dzt, xs[t], wp[t], dxs[t], dw, db, row_code=missing, code=codes[t], accumulate_dx=touched[t])
+            touched[t] = True
+            dwp.append(dw); dbp.append(db)
+            for s in range(n):
+                if s == t:
+                    continue
+                w = rw[t * n + s]
+                dw, db = torch.empty_like(w), torch.empty(F, **f32)
+                ops.small_linear_bwd(dzt, xs[s], w, dxs[s], dw, db, row_code=missing, code=codes[t], select=True, alpha=alpha,
+                                     accumulate_dx=touched[s])
+                touched[s] = True
+                drw[t * n + s], drb[t * n + s] = dw, db
+        return (None, None, None, *dxs, *dwp, *dbp, *drw, *drb)
+
+
+def fused_regression_concat(missing_index, codes: Sequence[int], xs, projs: Sequence[HipLinear], regs):
+    """regs[t][s]: HipLinear of the regressor s -> t, None for s == t"""
+    n = len(xs)
+    flat = [regs[t][s] for t in range(n) for s in range(n)]
+    return _RegressionConcatFn.apply(missing_index.contiguous(), tuple(int(c) for c in codes), n, *xs, *[l.weight for l in projs],
+                                     *[l.bias for l in projs], *[None if l is None else l.weight for l in flat],
+                                     *[None if l is None else l.bias for l in flat])
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

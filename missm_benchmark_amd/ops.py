@@ -251,14 +251,14 @@ def add_block(dst, src):
     _lib.call("missm_add_block", dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), B, W, _s())
 
 
-def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, x_sub=None, select=False, accumulate=False):
+def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, x_sub=None, select=False, alpha=1.0, accumulate=False):
     """y may be a column slice of a wider row-major buffer (its row stride is passed on)."""
     B, I = x.shape
     O = w.shape[0]
     if y.shape[0] < B or y.shape[1] != O or y.stride(1) != 1 or not x.is_contiguous() or not w.is_contiguous():
         raise _lib.MissmError("small_linear_fwd: bad operand layout")
     _lib.call("missm_small_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, I, O, y.stride(0), int(relu),
-              _p(row_code), int(code), _p(x_sub), int(select), int(accumulate), _s())
+              _p(row_code), int(code), _p(x_sub), int(select), float(alpha), int(accumulate), _s())
     return y
 
 
@@ -274,14 +274,14 @@ def gate_bwd(dy, d, pre, dd, dpre, *, row_code=None, code=0, accumulate_dd=False
               _p(row_code), int(code), int(accumulate_dd), _s())
 
 
-def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, x_sub=None, select=False, accumulate_dx=False,
-                     accumulate_dw=False):
+def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, code=0, x_sub=None, select=False, alpha=1.0,
+                     accumulate_dx=False, accumulate_dw=False):
     B, I = x.shape
     O = w.shape[0]
     if dy.shape[1] != O or dy.stride(1) != 1:
         raise _lib.MissmError("small_linear_bwd: bad dy layout")
     _lib.call("missm_small_linear_bwd", dy.data_ptr(), dy.stride(0), x.data_ptr(), w.data_ptr(), _p(relu_y), _p(dx), _p(dw), _p(dbias),
-              B, I, O, _p(row_code), int(code), _p(x_sub), int(select), int(accumulate_dx), int(accumulate_dw), _s())
+              B, I, O, _p(row_code), int(code), _p(x_sub), int(select), float(alpha), int(accumulate_dx), int(accumulate_dw), _s())
 
 
 def l2norm_scale_fwd(x, y, scale):

@@ -3,7 +3,7 @@
 ``finetune_model(args, output_dims, encoder_model)`` keeps the reference constructor / attributes / forward:
 ``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
 fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90), ``'retrieval'``
-(:164-180), ``'intra_attention'`` (:183-205) and ``'dedicated_dnn'`` (:333-353) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+(:164-180), ``'intra_attention'`` (:183-205), ``'dedicated_dnn'`` (:333-353) and ``'regression'`` (:93-161) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
 the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
 state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
 
@@ -146,7 +146,25 @@ class modal_dedicated_dnn(nn.Module):
         return self.head(self.norm(z))
 
 
-_NOT_YET = ("regression", "inter_attention", "graph_fusion", "unified_graph",
+class modal_regression(_FusionBase):
+    """Direct-to-task representation generation (reference :93-161): a missing modality's projection is predicted from the
+    other modalities by the ``cross_modal_regressors`` (``<source>_to_<target>``) and averaged."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim * len(args.modality_types))
+        if len(self.modality_types) < 2:
+            raise ValueError("regression needs at least two modalities")
+        self.cross_modal_regressors = nn.ModuleDict({f"{s}_to_{t}": hnn.HipLinear(args.feature_dims, args.fusion_dim)
+                                                     for s in self.modality_types for t in self.modality_types if s != t})
+
+    def forward(self, batch, missing_index):
+        mt = self.modality_types
+        regs = [[None if s == t else self.cross_modal_regressors[f"{s}_to_{t}"] for s in mt] for t in mt]
+        z = hnn.fused_regression_concat(missing_index, self._codes(), [batch[m] for m in mt], [self.modal_proj[m] for m in mt], regs)
+        return self.head(self.norm(z))
+
+
+_NOT_YET = ("inter_attention", "graph_fusion", "unified_graph",
             "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
 
 
@@ -165,6 +183,8 @@ class finetune_model(nn.Module):
             self.fusion = modal_intra_channel_attention(args, output_dims)
         elif args.fusion_type == "dedicated_dnn":
             self.fusion = modal_dedicated_dnn(args, output_dims)
+        elif args.fusion_type == "regression":
+            self.fusion = modal_regression(args, output_dims)
         elif args.fusion_type in _NOT_YET:
             raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
         else:

@@ -140,7 +140,8 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
     model = base.finetune_model(args, classes, _Enc()).eval()
     head_in = fusion_dim if fusion_type in ("sum", "intra_attention", "dedicated_dnn") else fusion_dim * len(modality_types)
     fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed, head_in=head_in,
-                              intra_attention=fusion_type == "intra_attention", dedicated=fusion_type == "dedicated_dnn")
+                              intra_attention=fusion_type == "intra_attention", dedicated=fusion_type == "dedicated_dnn",
+                              regression=fusion_type == "regression")
     model.fusion.load_state_dict(fp, strict=False)        # (the concat head also carries statistics_<modal> buffers)
     g = _gen(seed + 1)
     stats = None
@@ -169,6 +170,8 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
             lo = O.fusion_intra_attention(e0, missing, fp, modality_types)
         elif fusion_type == "dedicated_dnn":
             lo = O.fusion_dedicated_dnn(e0, missing, fp, modality_types)
+        elif fusion_type == "regression":
+            lo = O.fusion_regression(e0, missing, fp, modality_types)
         else:
             lo = O.fusion_concat(e0, missing, fp, modality_types, stats, mask=fusion_type == "concat")
     print(f"{name}: ref-vs-oracle logits {float((lo - logits).abs().max()):.2e}")
@@ -261,6 +264,8 @@ def main():
         seed=23, fusion_type="intra_attention")
     run(fusion_fixture, "fusion_dedicated_dnn", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
         seed=24, fusion_type="dedicated_dnn")
+    run(fusion_fixture, "fusion_regression", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
+        seed=25, fusion_type="regression")
     run(bundle_fixture, "bundle", seed=12)
     run(missing_fixture, "missing_index")
     # BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224 (weights by recipe, outputs stored)

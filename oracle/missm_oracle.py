@@ -342,6 +342,27 @@ def fusion_dedicated_dnn(emb: Dict[str, Tensor], missing_index: Tensor, fp: Para
     return head_forward(z, fp)
 
 
+def fusion_regression(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                      codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_regression.forward`` src/model/baseline.py:113-161: projections; where target t is missing, the mean over the
+    sources s != t that are present of ``cross_modal_regressors[s_to_t](x_s)`` replaces the projection; concat; LayerNorm; Head."""
+    proj = {m: F.linear(emb[m], fp[f"modal_proj.{m}.weight"], fp[f"modal_proj.{m}.bias"]) for m in modality_types}
+    for t in modality_types:
+        tmask = missing_index == codes[t]
+        preds, masks = [], []
+        for s in modality_types:
+            if s == t:
+                continue
+            preds.append(F.linear(emb[s], fp[f"cross_modal_regressors.{s}_to_{t}.weight"], fp[f"cross_modal_regressors.{s}_to_{t}.bias"]))
+            masks.append((missing_index != codes[s]).to(preds[-1].dtype))
+        p = torch.stack(preds, dim=1) * torch.stack(masks, dim=-1).unsqueeze(-1)
+        avg = p.sum(dim=1) / torch.stack(masks, dim=-1).unsqueeze(-1).sum(dim=1).clamp(min=1e-6)
+        proj[t] = torch.where(tmask[:, None], avg, proj[t])
+    z = torch.cat([proj[m] for m in modality_types], dim=-1)
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
@@ -439,7 +460,8 @@ def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
 
 
 def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
-                       seed: int, head_in: Optional[int] = None, intra_attention: bool = False, dedicated: bool = False) -> Params:
+                       seed: int, head_in: Optional[int] = None, intra_attention: bool = False, dedicated: bool = False,
+                       regression: bool = False) -> Params:
     """Seeded init for ``modal_sum`` / ``modal_concat`` / ``modal_concat_full`` + ``Head`` (src/model/baseline.py:27-50,66-71)
     parameter names; head_in = width of the fused row (fusion_dim for sum, fusion_dim * M for the concat heads)."""
     gen = torch.Generator().manual_seed(seed)
@@ -462,6 +484,12 @@ def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_
     fp["head.head.0.bias"] = _normal((fusion_dim,), 0.02, gen)
     fp["head.head.3.weight"] = _normal((num_classes, fusion_dim), fusion_dim ** -0.5, gen)
     fp["head.head.3.bias"] = _normal((num_classes,), 0.02, gen)
+    if regression:                               # modal_regression (:104-110)
+        for s in modality_types:
+            for t in modality_types:
+                if s != t:
+                    fp[f"cross_modal_regressors.{s}_to_{t}.weight"] = _normal((fusion_dim, feature_dims), feature_dims ** -0.5, gen)
+                    fp[f"cross_modal_regressors.{s}_to_{t}.bias"] = _normal((fusion_dim,), 0.02, gen)
     if intra_attention:                          # modal_intra_channel_attention (:190-196)
         fp["fusion_representation"] = _normal((1, fusion_dim), 1.0, gen)
         fp["channel_attention.0.weight"] = _normal((fusion_dim // 4, 2 * fusion_dim), (2 * fusion_dim) ** -0.5, gen)

@@ -112,7 +112,7 @@ def test_fusion_sum_and_loss():
         assert (fp[k].grad - g).abs().max() < TOL, k
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression"])
 def test_fusion_concat_heads(name):
     """modal_concat (imputation statistics set through set_statistics) and modal_concat_full against the reference's outputs"""
     fix = load_golden(name)
@@ -122,6 +122,8 @@ def test_fusion_concat_heads(name):
         logits = O.fusion_intra_attention(emb, fix["missing_index"], fp, fix["modality_types"])
     elif fix["fusion_type"] == "dedicated_dnn":
         logits = O.fusion_dedicated_dnn(emb, fix["missing_index"], fp, fix["modality_types"])
+    elif fix["fusion_type"] == "regression":
+        logits = O.fusion_regression(emb, fix["missing_index"], fp, fix["modality_types"])
     else:
         logits = O.fusion_concat(emb, fix["missing_index"], fp, fix["modality_types"], fix["statistics"], mask=fix["fusion_type"] == "concat")
     assert (logits - fix["logits"]).abs().max() < TOL

@@ -212,7 +212,7 @@ def test_fusion_sum_and_bundle_vs_reference_fixture(pkg, dtype, tol):
         assert rel(hnn.l2norm_scale(e, scale), ref) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression"])
 def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     """fusion_type 'concat' (zero / mean / median imputation through set_statistics, test.py:112-115) and 'retrieval':
     projections written straight into their slice of the concatenated row; logits, loss and every gradient against the
@@ -225,7 +225,7 @@ def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     model = pkg.base.finetune_model(args, C, torch.nn.Identity())
     assert type(model.fusion).__name__ == {"concat": "modal_concat", "retrieval": "modal_concat_full",
                                            "intra_attention": "modal_intra_channel_attention",
-                                           "dedicated_dnn": "modal_dedicated_dnn"}[fix["fusion_type"]]
+                                           "dedicated_dnn": "modal_dedicated_dnn", "regression": "modal_regression"}[fix["fusion_type"]]
     missing, unexpected = model.fusion.load_state_dict(fix["params"], strict=False)
     assert not unexpected and all(k.startswith("statistics_") for k in missing)
     model = model.cuda()
