@@ -148,6 +148,10 @@ int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const floa
                            int select, float alpha, int accumulate_dx, int accumulate_dw, void* stream);
 /* dst[b, 0:W] += src[b, 0:W] with row strides lddst / ldsrc (gradient slices of a concatenated feature row meeting again). */
 int missm_add_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, void* stream);
+/* dst[b, 0:W] = row_code[b] == code ? 0 : src[b, 0:W]: one modality's block of the concatenated feature row with its missing
+ * rows zeroed (the distillation heads, src/model/baseline.py:370-376); also its own backward. */
+int missm_masked_copy_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, const long* row_code, long code,
+                            void* stream);
 /* Channel-attention gate of the intra-modality attention head (src/model/baseline.py:198-201):
  * y[b,f] (= or +=) row b missing ? 0 : d[b,f] * sigmoid(pre[b,f]); d has row stride ldd.  Backward: dd (stride lddd, = or +=)
  * and dpre, both zero for missing rows. */

@@ -33,6 +33,7 @@ SIGNATURES = {
     "missm_argmax_rows": [P, P, I, I, P],
     "missm_small_linear_fwd": [P, P, P, P, I, I, I, I, I, P, L, P, I, F, I, P],
     "missm_add_block": [P, I, P, I, I, I, P],
+    "missm_masked_copy_block": [P, I, P, I, I, I, P, L, P],
     "missm_small_linear_bwd": [P, I, P, P, P, P, P, P, I, I, I, P, L, P, I, F, I, I, P],
     "missm_gate_fwd": [P, I, P, P, I, I, P, L, I, P],
     "missm_gate_bwd": [P, P, I, P, P, I, P, I, I, P, L, I, P],

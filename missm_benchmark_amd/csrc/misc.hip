@@ -383,6 +383,23 @@ __global__ __launch_bounds__(256) void add_block_kernel(float* __restrict__ dst,
   dst[(long)b * lddst + c] += src[(long)b * ldsrc + c];
 }
 
+// dst[b, 0:W] = row b carries the code ? 0 : src[b, 0:W]   (a modality's embedding block of the concatenated feature row with
+// its missing rows zeroed, src/model/baseline.py:370-374; the same kernel maps the gradient back)
+__global__ __launch_bounds__(256) void masked_copy_block_kernel(float* __restrict__ dst, int lddst, const float* __restrict__ src, int ldsrc,
+                                                               int B, int W, const long* __restrict__ row_code, long code) {
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)B * W) return;
+  const int b = idx / W, c = idx % W;
+  dst[(long)b * lddst + c] = (row_code && row_code[b] == code) ? 0.f : src[(long)b * ldsrc + c];
+}
+
+extern "C" int missm_masked_copy_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, const long* row_code, long code,
+                                       void* stream) {
+  MISSM_CHECK_ARG(B > 0 && W > 0 && lddst >= W && ldsrc >= W, "masked_copy_block: bad shape");
+  hipLaunchKernelGGL(masked_copy_block_kernel, dim3(((long)B * W + 255) / 256), dim3(256), 0, S_(stream), dst, lddst, src, ldsrc, B, W, row_code, code);
+  return missm_check_launch("masked_copy_block");
+}
+
 extern "C" int missm_add_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, void* stream) {
   MISSM_CHECK_ARG(B > 0 && W > 0 && lddst >= W && ldsrc >= W, "add_block: bad shape");
   hipLaunchKernelGGL(add_block_kernel, dim3(((long)B * W + 255) / 256), dim3(256), 0, S_(stream), dst, lddst, src, ldsrc, B, W);

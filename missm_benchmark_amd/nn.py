@@ -333,6 +333,38 @@ def fused_regression_concat(missing_index, codes: Sequence[int], xs, projs: Sequ
                                      *[None if l is None else l.bias for l in flat])
 
 
+class _MaskedConcatFn(torch.autograd.Function):
+    """features = cat_m where(missing == code_m, 0, x_m)  (reference src/model/baseline.py:370-374)"""
+
+    @staticmethod
+    def forward(ctx, missing, codes, *xs):
+        _gpu(xs[0], "masked concat")
+        xs = tuple(x.contiguous().float() for x in xs)
+        B, C = xs[0].shape
+        out = torch.empty(B, len(xs) * C, device=xs[0].device, dtype=torch.float32)
+        for i, x in enumerate(xs):
+            ops.masked_copy_block(out[:, i * C:(i + 1) * C], x, missing, codes[i])
+        ctx.save_for_backward(missing)
+        ctx.codes, ctx.C = codes, C
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        missing, = ctx.saved_tensors
+        dout = dout.contiguous()
+        C = ctx.C
+        dxs = []
+        for i, code in enumerate(ctx.codes):
+            dx = torch.empty(dout.shape[0], C, device=dout.device, dtype=torch.float32)
+            ops.masked_copy_block(dx, dout[:, i * C:(i + 1) * C], missing, code)
+            dxs.append(dx)
+        return (None, None, *dxs)
+
+
+def masked_concat(missing_index, codes: Sequence[int], xs):
+    return _MaskedConcatFn.apply(missing_index.contiguous(), tuple(int(c) for c in codes), *xs)
+
+
 class _LayerNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, b, eps):

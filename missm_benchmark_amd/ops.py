@@ -243,6 +243,14 @@ def argmax_rows(ids, out, B, S):
     return out
 
 
+def masked_copy_block(dst, src, row_code, code):
+    """dst = where(row_code == code, 0, src) for two [B, W] views with unit inner stride"""
+    B, W = src.shape
+    if dst.shape != src.shape or dst.stride(1) != 1 or src.stride(1) != 1:
+        raise _lib.MissmError("masked_copy_block: bad layout")
+    _lib.call("missm_masked_copy_block", dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), B, W, _p(row_code), int(code), _s())
+
+
 def add_block(dst, src):
     """dst += src for two [B, W] views with unit inner stride (column slices of wider buffers)"""
     B, W = src.shape

@@ -3,7 +3,8 @@
 ``finetune_model(args, output_dims, encoder_model)`` keeps the reference constructor / attributes / forward:
 ``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
 fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90), ``'retrieval'``
-(:164-180), ``'intra_attention'`` (:183-205), ``'dedicated_dnn'`` (:333-353) and ``'regression'`` (:93-161) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+(:164-180), ``'intra_attention'`` (:183-205), ``'dedicated_dnn'`` (:333-353), ``'regression'`` (:93-161) and the distillation network (``'Distill_tea'`` / ``'MTD_stu'`` /
+``'KL_stu'``, :356-380) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
 the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
 state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
 
@@ -164,8 +165,29 @@ class modal_regression(_FusionBase):
         return self.head(self.norm(z))
 
 
-_NOT_YET = ("inter_attention", "graph_fusion", "unified_graph",
-            "Distill_tea", "MTD_stu", "KL_stu", "self_distill")
+class modal_distillation(nn.Module):
+    """Teacher / student network of the distillation baselines (reference :356-380, fusion types Distill_tea, MTD_stu, KL_stu):
+    missing modalities zeroed, embeddings concatenated, Linear-ReLU-Linear, LayerNorm, Head; returns ``(features, logits)``."""
+
+    def __init__(self, args, output_dims):
+        super().__init__()
+        self.modality_types = list(args.modality_types)
+        seq = nn.Module()                                    # nn.Sequential keys of the reference: modal_proj.{0,2}.*
+        seq.add_module("0", hnn.HipLinear(args.feature_dims * len(self.modality_types), args.fusion_dim, relu=True))
+        seq.add_module("2", hnn.HipLinear(args.fusion_dim, args.fusion_dim))
+        self.modal_proj = seq
+        self.norm = hnn.HipLayerNorm(args.fusion_dim)
+        self.head = Head(args, args.fusion_dim, output_dims)
+
+    def forward(self, batch, missing_index):
+        features = hnn.masked_concat(missing_index, [missing_type_index[m] for m in self.modality_types],
+                                     [batch[m] for m in self.modality_types])
+        m = self.modal_proj._modules
+        inputs = m["2"](m["0"](features))
+        return features, self.head(self.norm(inputs))
+
+
+_NOT_YET = ("inter_attention", "graph_fusion", "unified_graph", "self_distill")
 
 
 class finetune_model(nn.Module):
@@ -185,6 +207,8 @@ class finetune_model(nn.Module):
             self.fusion = modal_dedicated_dnn(args, output_dims)
         elif args.fusion_type == "regression":
             self.fusion = modal_regression(args, output_dims)
+        elif args.fusion_type in ("Distill_tea", "MTD_stu", "KL_stu"):
+            self.fusion = modal_distillation(args, output_dims)
         elif args.fusion_type in _NOT_YET:
             raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
         else:

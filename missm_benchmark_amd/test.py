@@ -96,6 +96,7 @@ def test(args, train_loader: Iterable, test_loader: Dict[str, Dict[object, Itera
                         for data, label, missing_index in loader:
                             labels = (label["label"] if isinstance(label, dict) else label).to(args.device)
                             outputs = model(_prepare(data, args.device), missing_index.to(args.device))
+                            outputs = outputs[1] if isinstance(outputs, tuple) else outputs
                             total += float(criterion(outputs, labels))
                             nb += 1
                             probs.append(torch.softmax(outputs.float(), dim=-1).cpu().numpy())

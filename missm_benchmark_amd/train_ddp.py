@@ -10,7 +10,8 @@ checkpoint dictionaries (:298-306, :320-323) and early stopping (:311-313).  Wha
     iterable of ``(data, label, missing_index)`` batches shaped like the reference's (``data[m][k]`` tensors with the
     extra singleton dim the reference squeezes at :224-227 are accepted); ``synthetic_loader`` builds one for smoke runs;
   * checkpoints cannot be fetched by name (no network): see ``languagebind.LanguageBindModel.from_pretrained``.
-Distillation modes (MTD_stu / KL_stu / self_distill) need fusion heads that are queued.
+The distillation head itself (Distill_tea: teacher trained with CE) runs; the student modes (MTD_stu / KL_stu / self_distill) need the
+MSE / KL losses and the teacher plumbing, which are queued.
 """
 from __future__ import annotations
 
@@ -112,6 +113,7 @@ def evaluate(model: nn.Module, dataloader: Iterable, criterion, world_size: int,
             data = _prepare(data, device)
             labels = (label["label"] if isinstance(label, dict) else label).to(device)
             outputs = model(data, missing_index.to(device))
+            outputs = outputs[1] if isinstance(outputs, tuple) else outputs      # Distill_tea: (features, logits), train_ddp.py:108-111,247
             total += float(criterion(outputs, labels))
             nb += 1
             # softmax / argmax of a [B, C] logit block: host-side bookkeeping of the metrics, like the reference
@@ -178,6 +180,7 @@ def train(args, train_loader: Iterable, valid_loader: Iterable, output_dims: int
             data = _prepare(data, device)
             labels = (label["label"] if isinstance(label, dict) else label).to(device)
             outputs = model(data, missing_index.to(device))
+            outputs = outputs[1] if isinstance(outputs, tuple) else outputs      # Distill_tea: (features, logits), train_ddp.py:108-111,247
             loss = criterion(outputs, labels)
             loss.backward()
             engine.step()

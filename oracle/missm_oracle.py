@@ -363,6 +363,17 @@ def fusion_regression(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params,
     return head_forward(z, fp)
 
 
+def fusion_distillation(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                        codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tuple[Tensor, Tensor]:
+    """``modal_distillation.forward`` src/model/baseline.py:370-380: zero the missing modality, concatenate, Linear-ReLU-Linear,
+    LayerNorm, Head; returns (features, logits)."""
+    feats = torch.cat([torch.where((missing_index == codes[m])[:, None], torch.zeros_like(emb[m]), emb[m]) for m in modality_types], dim=-1)
+    h = F.relu(F.linear(feats, fp["modal_proj.0.weight"], fp["modal_proj.0.bias"]))
+    h = F.linear(h, fp["modal_proj.2.weight"], fp["modal_proj.2.bias"])
+    z = F.layer_norm(h, (h.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return feats, head_forward(z, fp)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
@@ -461,14 +472,19 @@ def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
 
 def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
                        seed: int, head_in: Optional[int] = None, intra_attention: bool = False, dedicated: bool = False,
-                       regression: bool = False) -> Params:
+                       regression: bool = False, distillation: bool = False) -> Params:
     """Seeded init for ``modal_sum`` / ``modal_concat`` / ``modal_concat_full`` + ``Head`` (src/model/baseline.py:27-50,66-71)
     parameter names; head_in = width of the fused row (fusion_dim for sum, fusion_dim * M for the concat heads)."""
     gen = torch.Generator().manual_seed(seed)
     head_in = fusion_dim if head_in is None else head_in
     fp: Params = {}
     M = len(modality_types)
-    if dedicated:                                # modal_dedicated_dnn (:339-343): no modal_proj
+    if distillation:                             # modal_distillation (:361-365): modal_proj is a Sequential over the concatenation
+        fp["modal_proj.0.weight"] = _normal((fusion_dim, feature_dims * M), (feature_dims * M) ** -0.5, gen)
+        fp["modal_proj.0.bias"] = _normal((fusion_dim,), 0.02, gen)
+        fp["modal_proj.2.weight"] = _normal((fusion_dim, fusion_dim), fusion_dim ** -0.5, gen)
+        fp["modal_proj.2.bias"] = _normal((fusion_dim,), 0.02, gen)
+    elif dedicated:                              # modal_dedicated_dnn (:339-343): no modal_proj
         for m in modality_types:
             fp[f"dedicated_dnn.{m}.weight"] = _normal((fusion_dim, feature_dims * (M - 1)), (feature_dims * (M - 1)) ** -0.5, gen)
             fp[f"dedicated_dnn.{m}.bias"] = _normal((fusion_dim,), 0.02, gen)

@@ -112,7 +112,8 @@ def test_fusion_sum_and_loss():
         assert (fp[k].grad - g).abs().max() < TOL, k
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression",
+                                  "fusion_distillation"])
 def test_fusion_concat_heads(name):
     """modal_concat (imputation statistics set through set_statistics) and modal_concat_full against the reference's outputs"""
     fix = load_golden(name)
@@ -124,11 +125,16 @@ def test_fusion_concat_heads(name):
         logits = O.fusion_dedicated_dnn(emb, fix["missing_index"], fp, fix["modality_types"])
     elif fix["fusion_type"] == "regression":
         logits = O.fusion_regression(emb, fix["missing_index"], fp, fix["modality_types"])
+    elif fix["fusion_type"] == "Distill_tea":
+        feats, logits = O.fusion_distillation(emb, fix["missing_index"], fp, fix["modality_types"])
+        assert (feats - fix["features"]).abs().max() < TOL
     else:
         logits = O.fusion_concat(emb, fix["missing_index"], fp, fix["modality_types"], fix["statistics"], mask=fix["fusion_type"] == "concat")
     assert (logits - fix["logits"]).abs().max() < TOL
     loss = O.cross_entropy(logits, fix["labels"])
     assert abs(float(loss.detach()) - float(fix["loss"])) < TOL
+    if fix.get("features") is not None:
+        loss = loss + (feats * fix["cot_features"]).sum()
     loss.backward()
     for m in emb:
         assert (emb[m].grad - fix["emb_grads"][m]).abs().max() < TOL

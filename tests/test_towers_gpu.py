@@ -212,7 +212,8 @@ def test_fusion_sum_and_bundle_vs_reference_fixture(pkg, dtype, tol):
         assert rel(hnn.l2norm_scale(e, scale), ref) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression",
+                                  "fusion_distillation"])
 def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     """fusion_type 'concat' (zero / mean / median imputation through set_statistics, test.py:112-115) and 'retrieval':
     projections written straight into their slice of the concatenated row; logits, loss and every gradient against the
@@ -225,7 +226,8 @@ def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     model = pkg.base.finetune_model(args, C, torch.nn.Identity())
     assert type(model.fusion).__name__ == {"concat": "modal_concat", "retrieval": "modal_concat_full",
                                            "intra_attention": "modal_intra_channel_attention",
-                                           "dedicated_dnn": "modal_dedicated_dnn", "regression": "modal_regression"}[fix["fusion_type"]]
+                                           "dedicated_dnn": "modal_dedicated_dnn", "regression": "modal_regression",
+                                           "Distill_tea": "modal_distillation"}[fix["fusion_type"]]
     missing, unexpected = model.fusion.load_state_dict(fix["params"], strict=False)
     assert not unexpected and all(k.startswith("statistics_") for k in missing)
     model = model.cuda()
@@ -234,10 +236,16 @@ def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
         assert all(f"statistics_{m}" in model.fusion.state_dict() for m in mt)
     emb = {m: e.cuda().requires_grad_(True) for m, e in fix["emb"].items()}
     logits = model(emb, fix["missing_index"].cuda())
+    feats = None
+    if isinstance(logits, tuple):                     # distillation heads: (features, logits)
+        feats, logits = logits
+        assert rel(feats, fix["features"]) < 1e-6
     assert rel(logits, fix["logits"]) < 1e-5
     from missm_benchmark_amd.nn import HipCrossEntropyLoss
     loss = HipCrossEntropyLoss()(logits, fix["labels"].cuda())
-    assert abs(float(loss) - float(fix["loss"])) < 1e-5
+    assert abs(float(loss.detach()) - float(fix["loss"])) < 1e-5
+    if feats is not None:
+        feats.backward(fix["cot_features"].cuda(), retain_graph=True)     # the distillation losses' path into the features
     loss.backward()
     for m in mt:
         assert rel(emb[m].grad, fix["emb_grads"][m]) < 1e-4, m
