@@ -4,7 +4,7 @@
 ``forward(data, missing_index) = fusion(encoder(data), missing_index)``; ``args`` needs ``modality_types, feature_dims,
 fusion_dim, dropout_prob, fusion_type``.  ``'concat'`` (zero / mean / median imputation, reference :64-90), ``'retrieval'``
 (:164-180), ``'intra_attention'`` (:183-205), ``'dedicated_dnn'`` (:333-353), ``'regression'`` (:93-161) and the distillation network (``'Distill_tea'`` / ``'MTD_stu'`` /
-``'KL_stu'``, :356-380) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
+``'KL_stu'``, :356-380; ``'self_distill'``, :383-418) are available too.  The primary head (``fusion_type == 'sum'``: per-modality projection, zeroing of
 the missing modality's rows, sum, LayerNorm, MLP head) runs on the HIP kernels; its parameters keep the reference's
 state-dict keys (``fusion.modal_proj.<m>.{weight,bias}``, ``fusion.norm.*``, ``fusion.head.head.{0,3}.*``).
 
@@ -187,7 +187,34 @@ class modal_distillation(nn.Module):
         return features, self.head(self.norm(inputs))
 
 
-_NOT_YET = ("inter_attention", "graph_fusion", "unified_graph", "self_distill")
+class modal_self_distillation(modal_distillation):
+    """Self distillation (reference :383-418): the same network; in training it also returns, per modality, the student
+    features computed from that modality alone (the other blocks of the concatenated row are zero) next to the teacher features
+    of the full row: ``(missing_mask, stu_features, tea_features, logits)``.  In eval: logits only."""
+
+    def _project(self, features):
+        m = self.modal_proj._modules
+        return m["2"](m["0"](features))
+
+    def forward(self, batch, missing_index):
+        mt = self.modality_types
+        codes = [missing_type_index[m] for m in mt]
+        xs = [batch[m] for m in mt]
+        tea = self._project(hnn.masked_concat(missing_index, codes, xs))
+        if not self.training:
+            return self.head(self.norm(tea))
+        never = -1                                  # a code no sample carries: blocks of the other modalities are all-zero inputs
+        stu, masks = [], []
+        for i, m in enumerate(mt):
+            zeros = [torch.zeros_like(x) for x in xs]
+            only_i = hnn.masked_concat(missing_index, [codes[j] if j == i else never for j in range(len(mt))],
+                                       [xs[j] if j == i else zeros[j] for j in range(len(mt))])
+            stu.append(self._project(only_i))
+            masks.append(missing_index != codes[i])
+        return masks, stu, tea, self.head(self.norm(tea))
+
+
+_NOT_YET = ("inter_attention", "graph_fusion", "unified_graph")
 
 
 class finetune_model(nn.Module):
@@ -209,6 +236,8 @@ class finetune_model(nn.Module):
             self.fusion = modal_regression(args, output_dims)
         elif args.fusion_type in ("Distill_tea", "MTD_stu", "KL_stu"):
             self.fusion = modal_distillation(args, output_dims)
+        elif args.fusion_type == "self_distill":
+            self.fusion = modal_self_distillation(args, output_dims)
         elif args.fusion_type in _NOT_YET:
             raise NotImplementedError(f"fusion_type {args.fusion_type!r} is queued behind the 'sum' hot path (SURVEY.md 8f rank 2)")
         else:

@@ -10,7 +10,7 @@ checkpoint dictionaries (:298-306, :320-323) and early stopping (:311-313).  Wha
     iterable of ``(data, label, missing_index)`` batches shaped like the reference's (``data[m][k]`` tensors with the
     extra singleton dim the reference squeezes at :224-227 are accepted); ``synthetic_loader`` builds one for smoke runs;
   * checkpoints cannot be fetched by name (no network): see ``languagebind.LanguageBindModel.from_pretrained``.
-The distillation head itself (Distill_tea: teacher trained with CE) runs; the student modes (MTD_stu / KL_stu / self_distill) need the
+The distillation heads themselves run (Distill_tea: teacher trained with CE); the student training modes (MTD_stu / KL_stu / self_distill) need the
 MSE / KL losses and the teacher plumbing, which are queued.
 """
 from __future__ import annotations

@@ -138,10 +138,10 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
             return data
 
     model = base.finetune_model(args, classes, _Enc()).eval()
-    head_in = fusion_dim if fusion_type in ("sum", "intra_attention", "dedicated_dnn", "Distill_tea") else fusion_dim * len(modality_types)
+    head_in = fusion_dim if fusion_type in ("sum", "intra_attention", "dedicated_dnn", "Distill_tea", "self_distill") else fusion_dim * len(modality_types)
     fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed, head_in=head_in,
                               intra_attention=fusion_type == "intra_attention", dedicated=fusion_type == "dedicated_dnn",
-                              regression=fusion_type == "regression", distillation=fusion_type == "Distill_tea")
+                              regression=fusion_type == "regression", distillation=fusion_type in ("Distill_tea", "self_distill"))
     model.fusion.load_state_dict(fp, strict=False)        # (the concat head also carries statistics_<modal> buffers)
     g = _gen(seed + 1)
     stats = None
@@ -155,17 +155,27 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
     # (non-leaf copies, as encoder outputs are: modal_concat overwrites the missing rows of its inputs in place, :82)
     logits = model({m: e * 1.0 for m, e in emb.items()}, missing)
     features = cot_features = None
-    if isinstance(logits, tuple):                          # distillation heads return (features, logits), :380
+    extra = None
+    if fusion_type == "self_distill":                      # training mode: (missing_mask, stu_features, tea_features, logits), :411
+        model.train()
+        masks, stu, tea, logits = model({m: e * 1.0 for m, e in emb.items()}, missing)
+        cots = [torch.randn(t.shape, generator=g) * 0.01 for t in stu + [tea]]
+        extra = {"masks": [m.clone() for m in masks], "stu": [t.detach() for t in stu], "tea": tea.detach(), "cots": cots}
+        aux = sum((t * c).sum() for t, c in zip(stu + [tea], cots))
+    elif isinstance(logits, tuple):                        # distillation heads return (features, logits), :380
         features, logits = logits
         cot_features = torch.randn(features.shape, generator=g) * 0.01
+        aux = (features * cot_features).sum()
+    else:
+        aux = 0.0
     loss = torch.nn.CrossEntropyLoss()(logits, labels)
-    (loss if features is None else loss + (features * cot_features).sum()).backward()
+    (loss + aux).backward()
     fix = {"modality_types": list(modality_types), "params": fp, "emb": {m: e.detach() for m, e in emb.items()},
            "missing_index": missing, "labels": labels, "logits": logits.detach(), "loss": loss.detach(),
            "emb_grads": {m: e.grad.clone() for m, e in emb.items()},
            "grads": {k: v.grad.clone() for k, v in model.fusion.named_parameters()},
            "missing_type_index": dict(base.missing_type_index), "fusion_type": fusion_type, "statistics": stats,
-           "features": None if features is None else features.detach(), "cot_features": cot_features}
+           "features": None if features is None else features.detach(), "cot_features": cot_features, "self_distill": extra}
     torch.save(fix, os.path.join(OUT, name + ".pt"))
     with torch.no_grad():
         e0 = {m: e.detach() for m, e in emb.items()}
@@ -179,6 +189,8 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
             lo = O.fusion_regression(e0, missing, fp, modality_types)
         elif fusion_type == "Distill_tea":
             lo = O.fusion_distillation(e0, missing, fp, modality_types)[1]
+        elif fusion_type == "self_distill":
+            lo = O.fusion_self_distillation(e0, missing, fp, modality_types)[3]
         else:
             lo = O.fusion_concat(e0, missing, fp, modality_types, stats, mask=fusion_type == "concat")
     print(f"{name}: ref-vs-oracle logits {float((lo - logits).abs().max()):.2e}")
@@ -275,6 +287,8 @@ def main():
         seed=25, fusion_type="regression")
     run(fusion_fixture, "fusion_distillation", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
         seed=26, fusion_type="Distill_tea")
+    run(fusion_fixture, "fusion_self_distill", ["language", "video", "image"], batch=9, feature_dims=48, fusion_dim=32, classes=4,
+        seed=27, fusion_type="self_distill")
     run(bundle_fixture, "bundle", seed=12)
     run(missing_fixture, "missing_index")
     # BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224 (weights by recipe, outputs stored)

@@ -374,6 +374,22 @@ def fusion_distillation(emb: Dict[str, Tensor], missing_index: Tensor, fp: Param
     return feats, head_forward(z, fp)
 
 
+def fusion_self_distillation(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                             codes: Dict[str, int] = MISSING_TYPE_INDEX):
+    """``modal_self_distillation.forward`` in training mode, src/model/baseline.py:397-411:
+    (missing_mask list, student features per modality, teacher features, logits)."""
+    def proj(f):
+        return F.linear(F.relu(F.linear(f, fp["modal_proj.0.weight"], fp["modal_proj.0.bias"])), fp["modal_proj.2.weight"], fp["modal_proj.2.bias"])
+    masked = [torch.where((missing_index == codes[m])[:, None], torch.zeros_like(emb[m]), emb[m]) for m in modality_types]
+    stu, masks = [], []
+    for i, m in enumerate(modality_types):
+        stu.append(proj(torch.cat([masked[j] if j == i else torch.zeros_like(masked[j]) for j in range(len(masked))], dim=-1)))
+        masks.append(missing_index != codes[m])
+    tea = proj(torch.cat(masked, dim=-1))
+    z = F.layer_norm(tea, (tea.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return masks, stu, tea, head_forward(z, fp)
+
+
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)

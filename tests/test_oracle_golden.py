@@ -169,3 +169,20 @@ def test_adam_matches_torch_optim():
         opt.step()
         O.adam_step(p, grad, m, v, step, 1e-3)
     assert (p - ref.detach()).abs().max() < 1e-6
+
+
+def test_fusion_self_distillation_training_outputs():
+    """modal_self_distillation in training mode: masks, per-modality student features, teacher features, logits and gradients"""
+    fix = load_golden("fusion_self_distill")
+    fp = {k: v.clone().requires_grad_(True) for k, v in fix["params"].items()}
+    emb = {m: e.clone().requires_grad_(True) for m, e in fix["emb"].items()}
+    masks, stu, tea, logits = O.fusion_self_distillation(emb, fix["missing_index"], fp, fix["modality_types"])
+    sd = fix["self_distill"]
+    assert all(torch.equal(a, b) for a, b in zip(masks, sd["masks"]))
+    assert all((a - b).abs().max() < TOL for a, b in zip(stu, sd["stu"])) and (tea - sd["tea"]).abs().max() < TOL
+    assert (logits - fix["logits"]).abs().max() < TOL
+    (O.cross_entropy(logits, fix["labels"]) + sum((t * c).sum() for t, c in zip(stu + [tea], sd["cots"]))).backward()
+    for m in emb:
+        assert (emb[m].grad - fix["emb_grads"][m]).abs().max() < TOL
+    for k, g in fix["grads"].items():
+        assert (fp[k].grad - g).abs().max() < TOL, k
