@@ -122,10 +122,13 @@ int missm_cast_rows(const float* in, void* out, long R, int C, int rdiv, int rof
 /* x[n, s, :] = (s == 0 ? cls : patches[n*(S-1) + s-1]) + pos[s]   (CLIPVisionEmbeddings, video/modeling_video.py:48-50). */
 int missm_embed_assemble(const void* patches, const float* cls, const float* pos, float* x, int N, int S, int d, int dtype,
                          void* stream);
-/* h[b, s, :] = tok[ids[b, s]] + pos[s]  (CLIPTextEmbeddings, third-party; image/modeling_image.py:494). */
-int missm_token_embed_fwd(const long* ids, const float* tok, const float* pos, float* h, int B, int S, int d, void* stream);
-/* dtok[ids[b,s]] += dh[b,s] (atomic), dpos[s] += sum_b dh[b,s]. */
-int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* dpos, int B, int S, int d, void* stream);
+/* h[b, s, :] = tok[ids[b, s]] + pos[s]  (CLIPTextEmbeddings, third-party; image/modeling_image.py:494).  An id outside
+ * [0, vocab) never reaches memory: its row is filled with NaN (the reference raises IndexError / a device-side assert). */
+int missm_token_embed_fwd(const long* ids, const float* tok, const float* pos, float* h, int B, int S, int d, int vocab,
+                          void* stream);
+/* dtok[ids[b,s]] += dh[b,s] (atomic), dpos[s] += sum_b dh[b,s]; rows whose id is outside [0, vocab) are skipped. */
+int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* dpos, int B, int S, int d, int vocab,
+                          void* stream);
 /* eot[b] = argmax_s ids[b, s] (first occurrence), image/modeling_image.py:519-522. */
 int missm_argmax_rows(const long* ids, int* out, int B, int S, void* stream);
 

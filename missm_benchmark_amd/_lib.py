@@ -28,8 +28,8 @@ SIGNATURES = {
     "missm_attention_bwd": [P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, P, F, I, P],
     "missm_unfold_patches": [P, P, I, I, I, I, I, I, L, L, L, I, P],
     "missm_embed_assemble": [P, P, P, P, I, I, I, I, P],
-    "missm_token_embed_fwd": [P, P, P, P, I, I, I, P],
-    "missm_token_embed_bwd": [P, P, P, P, I, I, I, P],
+    "missm_token_embed_fwd": [P, P, P, P, I, I, I, I, P],
+    "missm_token_embed_bwd": [P, P, P, P, I, I, I, I, P],
     "missm_argmax_rows": [P, P, I, I, P],
     "missm_small_linear_fwd": [P, P, P, P, I, I, I, I, I, P, L, P, I, F, I, P],
     "missm_add_block": [P, I, P, I, I, I, P],
@@ -48,7 +48,7 @@ SIGNATURES = {
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
-ABI_VERSION = 2     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 3     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

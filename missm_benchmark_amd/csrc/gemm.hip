@@ -16,6 +16,7 @@
 #include <stdlib.h>
 #include <math.h>
 #include <mutex>
+#include <type_traits>
 #include <unordered_map>
 
 namespace missm {
@@ -624,6 +625,10 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
   }
 }
 
+}  // namespace missm
+#include "gemm8p.h"
+namespace missm {
+
 // Measured and removed again (git history has them; all correct, none faster on the hot-path shapes):
 //   * 256x128 / 8 waves / 3-stage ring with counted vmcnt, one workgroup per CU : 845 TFLOP/s at 4096^3, 570-750 on the
 //     K = 768 video shapes (every tile's fill/drain is exposed with a single resident workgroup);
@@ -940,6 +945,21 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
       const int tmb = (g.M + 255) / 256;
       g.tiles_m = tmb; g.tiles_n = tn2;
       g.group_m = group_m_env > 0 ? group_m_env : (tn2 >= 4 ? 8 : 1);
+      // 8-wave / 8-phase pipeline (gemm8p.h): whole pairs of K tiles, vector epilogue only
+      static const int use8p = getenv("MISSM_GEMM_8P") ? atoi(getenv("MISSM_GEMM_8P")) : 1;
+      if (use8p && K % 128 == 0 && (size_t)lda * 2 * 128 < (size_t(1) << 31) && (size_t)ldb * 2 * 256 < (size_t(1) << 31)) {
+        auto k8 = use8p == 2 ? gemm8p_kernel<false> : gemm8p_kernel<true>;
+        static bool attr8[2] = {false, false};
+        if (!attr8[use8p == 2]) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+            missm_set_error("gemm: cannot raise dynamic LDS to 128 KiB");
+            return MISSM_ERR_LAUNCH;
+          }
+          attr8[use8p == 2] = true;
+        }
+        hipLaunchKernelGGL(k8, dim3(tmb * tn2), dim3(512), 128 * 1024, s, g);
+        return missm_check_launch("gemm8p");
+      }
       auto k = gemm_kernel<bf16, false, false, 128, 1, 4>;
       static bool attr_set = false;
       if (!attr_set) {

@@ -41,28 +41,39 @@ __global__ __launch_bounds__(256) void embed_assemble_kernel(const T* __restrict
 }
 
 __global__ __launch_bounds__(256) void token_embed_fwd_kernel(const long* __restrict__ ids, const float* __restrict__ tok,
-                                                             const float* __restrict__ pos, float* __restrict__ h, int B, int S, int d) {
+                                                             const float* __restrict__ pos, float* __restrict__ h, int B, int S, int d,
+                                                             int vocab) {
   const int q4 = d / 4;
   const long total = (long)B * S * q4;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = (idx % q4) * 4;
     const long row = idx / q4;
     const int s = row % S;
-    f32x4 v = load4(tok + ids[row] * d + c);
-    v += load4(pos + (long)s * d + c);
+    const long id = ids[row];
+    f32x4 v;
+    if (id >= 0 && id < vocab) {
+      v = load4(tok + id * d + c);
+      v += load4(pos + (long)s * d + c);
+    } else {
+      const float nan = __builtin_nanf("");       // out-of-range id: poison the row instead of reading out of bounds
+      v = f32x4{nan, nan, nan, nan};
+    }
     store4(h + row * d + c, v);
   }
 }
 
 __global__ __launch_bounds__(256) void token_embed_bwd_kernel(const long* __restrict__ ids, const float* __restrict__ dh,
-                                                             float* __restrict__ dtok, float* __restrict__ dpos, int B, int S, int d) {
+                                                             float* __restrict__ dtok, float* __restrict__ dpos, int B, int S, int d,
+                                                             int vocab) {
   const long total = (long)B * S * d;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int c = idx % d;
     const long row = idx / d;
     const int s = row % S;
     const float g = dh[idx];
-    atomicAdd(dtok + ids[row] * d + c, g);
+    const long id = ids[row];
+    if (id < 0 || id >= vocab) continue;
+    atomicAdd(dtok + id * d + c, g);
     atomicAdd(dpos + (long)s * d + c, g);
   }
 }
@@ -127,8 +138,10 @@ __device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* 
   return g;
 }
 
-// dx[b, i] (+)= sum_o dyeff[b, o] w[o, i] ; the reduction over o is split across blockIdx.y (32 outputs per slice,
-// partial sums added atomically into a zeroed / accumulated dx) so the launch fills the chip instead of 96 workgroups
+// dx[b, i] (+)= sum_o dyeff[b, o] w[o, i].  One thread per element, the whole reduction over o in a FIXED order (four
+// interleaved partial sums, combined pairwise): the result is bit-reproducible from run to run.  (The first version split o
+// over blockIdx.y and met in fp32 atomics; the arrival order changed the last bits of the gradient that enters the towers, and
+// their bf16 backward amplifies a 1-ulp difference into 1e-3-level differences of the weight gradients.)
 __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
                                                              int lddy, const long* __restrict__ row_code, long code, int select, float alpha,
@@ -136,10 +149,17 @@ __global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __res
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * I) return;
   const int b = idx / I, i = idx % I;
-  const int o0 = blockIdx.y * 32, o1 = min(O, o0 + 32);
-  float acc = 0.f;
-  for (int o = o0; o < o1; ++o) acc += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
-  atomicAdd(dx + idx, acc * alpha);
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int o = 0;
+  for (; o + 3 < O; o += 4) {
+    a0 += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
+    a1 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 1, O, select) * w[(long)(o + 1) * I + i];
+    a2 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 2, O, select) * w[(long)(o + 2) * I + i];
+    a3 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 3, O, select) * w[(long)(o + 3) * I + i];
+  }
+  for (; o < O; ++o) a0 += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
+  const float acc = ((a0 + a1) + (a2 + a3)) * alpha;
+  dx[idx] = accumulate ? dx[idx] + acc : acc;
 }
 
 // dw[o, i] = sum_b dyeff[b, o] x[b, i] ; dbias[o] = sum_b dyeff[b, o]
@@ -233,7 +253,7 @@ __global__ __launch_bounds__(64) void cross_entropy_kernel(const float* __restri
     for (int c = 0; c < C; ++c) s += expf(lr[c] - mx);
     const float lse = mx + logf(s);
     const long y = labels[b];
-    part += lse - lr[y];
+    part += (y >= 0 && y < C) ? lse - lr[y] : __builtin_nanf("");   // out-of-range label: NaN loss, no out-of-bounds read
     if (dlogits)
       for (int c = 0; c < C; ++c) dlogits[(long)b * C + c] = (expf(lr[c] - lse) - (c == y ? 1.f : 0.f)) / B;
   }
@@ -332,15 +352,17 @@ extern "C" int missm_embed_assemble(const void* patches, const float* cls, const
   return missm_check_launch("embed_assemble");
 }
 
-extern "C" int missm_token_embed_fwd(const long* ids, const float* tok, const float* pos, float* h, int B, int S, int d, void* stream) {
-  MISSM_CHECK_ARG(B > 0 && S > 0 && d > 0 && d % 4 == 0, "token_embed_fwd: bad shape");
-  hipLaunchKernelGGL(token_embed_fwd_kernel, dim3(grid_for((long)B * S * (d / 4))), dim3(256), 0, S_(stream), ids, tok, pos, h, B, S, d);
+extern "C" int missm_token_embed_fwd(const long* ids, const float* tok, const float* pos, float* h, int B, int S, int d, int vocab,
+                                     void* stream) {
+  MISSM_CHECK_ARG(B > 0 && S > 0 && d > 0 && d % 4 == 0 && vocab > 0, "token_embed_fwd: bad shape");
+  hipLaunchKernelGGL(token_embed_fwd_kernel, dim3(grid_for((long)B * S * (d / 4))), dim3(256), 0, S_(stream), ids, tok, pos, h, B, S, d, vocab);
   return missm_check_launch("token_embed_fwd");
 }
 
-extern "C" int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* dpos, int B, int S, int d, void* stream) {
-  MISSM_CHECK_ARG(B > 0 && S > 0 && d > 0, "token_embed_bwd: bad shape");
-  hipLaunchKernelGGL(token_embed_bwd_kernel, dim3(grid_for((long)B * S * d)), dim3(256), 0, S_(stream), ids, dh, dtok, dpos, B, S, d);
+extern "C" int missm_token_embed_bwd(const long* ids, const float* dh, float* dtok, float* dpos, int B, int S, int d, int vocab,
+                                     void* stream) {
+  MISSM_CHECK_ARG(B > 0 && S > 0 && d > 0 && vocab > 0, "token_embed_bwd: bad shape");
+  hipLaunchKernelGGL(token_embed_bwd_kernel, dim3(grid_for((long)B * S * d)), dim3(256), 0, S_(stream), ids, dh, dtok, dpos, B, S, d, vocab);
   return missm_check_launch("token_embed_bwd");
 }
 
@@ -368,8 +390,7 @@ extern "C" int missm_small_linear_bwd(const float* dy, int lddy, const float* x,
   MISSM_CHECK_ARG(!relu_y || lddy == O, "small_linear_bwd: the relu mask is dense, dy must be too");
   MISSM_CHECK_ARG(!relu_y || alpha == 1.0f, "small_linear_bwd: alpha with a fused ReLU is not supported");
   if (dx) {
-    if (!accumulate_dx) { if (hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * I, S_(stream)) != hipSuccess) { missm_set_error("small_linear_bwd: memset failed"); return MISSM_ERR_LAUNCH; } }
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256, (O + 31) / 32), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, alpha, accumulate_dx);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, alpha, accumulate_dx);
   }
   if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, select, alpha, accumulate_dw);
   return missm_check_launch("small_linear_bwd");

@@ -26,6 +26,9 @@ from . import ops
 from .towers import ClipTower
 
 
+import contextlib
+
+_null = contextlib.nullcontext
 _FUSED_UPDATE = os.environ.get("MISSM_FUSED_ADAM", "1") != "0"   # A/B switch: Adam fused with the weight-shadow refresh
 
 
@@ -60,28 +63,46 @@ class FlatGroup:
 
 class TrainEngine:
     def __init__(self, model: nn.Module, lr: float = 1e-4, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
-                 process_group=None, overlap: bool = True, eager_step: bool = True):
+                 process_group=None, overlap: bool = True, eager_step: bool = False):
         self.model = model
         self.lr, self.betas, self.eps, self.wd = lr, betas, eps, weight_decay
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
-        self.towers: List[ClipTower] = [m for m in model.modules() if isinstance(m, ClipTower)]
-        owned = {id(p) for t in self.towers for p in t.parameters()}
+        self.towers: List[ClipTower] = []
+        frozen_towers = []
+        for m in model.modules():
+            if not isinstance(m, ClipTower):
+                continue
+            flags = {p.requires_grad for p in m.parameters()}
+            if flags == {False}:
+                frozen_towers.append(m)      # a frozen tower (e.g. a distillation teacher's encoder) is simply not optimised
+            elif flags == {True}:
+                self.towers.append(m)
+            else:
+                # the optimizer and the all-reduce address a tower as ONE flat buffer: per-parameter freezing inside a tower
+                # would still be updated (weight decay / stale Adam moments) - refuse instead of doing that silently
+                raise NotImplementedError("TrainEngine: a tower must be trainable or frozen as a whole (requires_grad differs "
+                                          "between its parameters)")
+        owned = {id(p) for t in self.towers + frozen_towers for p in t.parameters()}
         rest = [p for p in model.parameters() if id(p) not in owned and p.requires_grad]
         self.rest = FlatGroup(rest) if rest else None
         self.step_count = 0
         self._state = {}
         self._pending = []
         self.overlap = overlap and self.world > 1
-        # eager_step: a tower's Adam update (and the refresh of its bf16 weight copies) is enqueued as soon as its gradient
-        # is final - right behind its backward (1 GPU) or behind its all-reduce on the communication stream (N GPUs) -
-        # instead of serialising every optimizer launch after the whole backward.  One backward per step is assumed.
+        # eager_step (opt-in; bench.py and train_ddp.train turn it on): a tower's Adam update (and the refresh of its bf16
+        # weight copies) is enqueued as soon as its gradient is final - right behind its backward (1 GPU) or behind its
+        # all-reduce on the communication stream (N GPUs) - instead of serialising every optimizer launch after the whole
+        # backward.  That means ``loss.backward()`` itself updates the towers' weights: it is only valid for loops that run
+        # exactly ONE backward per tower per step (the reference's loop, train_ddp.py:249-254) and never read or clip
+        # ``.grad`` before ``step()``; a second backward of a tower before ``step()`` raises.
         self.eager_step = eager_step
         self._eager_done = set()
         self._host_sync_before_collective = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
         self.comm_stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
         for t in self.towers:
             t._post_backward = self._tower_done if (self.world > 1 or eager_step) else None
+            t._bucket_hook = self._bucket_ready if self.overlap else None
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -114,16 +135,35 @@ class TrainEngine:
             h = dist.all_reduce(grad, op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         self._pending.append(h)
 
+    def _bucket_ready(self, tower: ClipTower, lo: int, hi: int):
+        """called from inside a tower's backward: flat range [lo, hi) of its gradient is final (reverse execution order, like
+        DDP's buckets - train_ddp.py:188-189,253 - but as a few 85-115 MB messages: xGMI rings are per-link bound)"""
+        if tower._accumulate:
+            raise RuntimeError("TrainEngine(overlap=True): accumulating backward (see _tower_done)")
+        self._all_reduce_async(tower.flat_grad()[lo:hi])
+
     def _tower_done(self, tower: ClipTower):
         """called by the tower's backward on the stream it ran on, after its last kernel was enqueued"""
+        if id(tower) in self._eager_done:
+            raise RuntimeError("TrainEngine(eager_step=True): a tower ran a second backward before step(); its weights were "
+                               "already updated by the first one.  Use eager_step=False for gradient accumulation or models "
+                               "that call one tower twice per step.")
+        if self.world > 1 and self.overlap and tower._accumulate:
+            raise RuntimeError("TrainEngine(overlap=True) all-reduces a tower's gradient right behind its backward: a second, "
+                               "accumulating backward before step() would be reduced twice.  Use overlap=False for gradient "
+                               "accumulation.")
         if self.world > 1:
             if not self.overlap:
                 return
-            self._all_reduce_async(tower.flat_grad())
+            lo, hi = tower.tail_range()           # the layer buckets left during the backward (_bucket_ready); this is the rest
+            self._all_reduce_async(tower.flat_grad()[lo:hi])
             if self.eager_step and tower.flat_master().is_cuda:
-                h = self._pending.pop()
-                with torch.cuda.stream(self.comm_stream):
-                    h.wait()                      # comm stream waits for the reduction, then updates this tower
+                # every reduction of this tower was issued from this thread, in order; waiting for all pending handles on the
+                # communication stream orders the update behind them (other towers' handles are at most a few buckets)
+                hs, self._pending = self._pending, []
+                with torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _null():
+                    for h in hs:
+                        h.wait()                  # comm stream waits for the reductions, then updates this tower
                     self._adam_on(tower.flat_master(), tower.flat_grad(), tower)
                     tower._ensure_ready()
                 self._eager_done.add(id(tower))
@@ -133,6 +173,10 @@ class TrainEngine:
             self._eager_done.add(id(tower))
 
     def zero_grad(self):
+        """forget every gradient: the flattened remainder is cleared, the towers' next backward overwrites (instead of
+        accumulating into) their buffers"""
+        for t in self.towers:
+            t._grad_fresh = False
         if self.rest is not None:
             self.rest.reattach()
             self.rest.grad.zero_()
@@ -182,6 +226,7 @@ class TrainEngine:
         all-reduce is folded in"""
         for master, grad, t in self.flat_buffers():
             if t is not None and (id(t) in self._eager_done or not t._grad_fresh):
+                t._grad_fresh = False
                 continue   # updated eagerly, or not used this step (e.g. no 'language' input: gradient None in the reference)
             self._adam_on(master, grad, t)
         self._eager_done.clear()
@@ -190,3 +235,28 @@ class TrainEngine:
     def step(self):
         self.reduce_gradients()
         self.apply_adam()
+
+    # ---- optimizer state (checkpoint 'optimizer_state_dict', reference train_ddp.py:298-306) -----------------------
+    def state_dict(self):
+        """step count, hyper-parameters and the Adam moments of every flat buffer (in flat_buffers() order), on the CPU"""
+        torch.cuda.synchronize() if torch.cuda.is_available() else None
+        flat = []
+        for master, _, _ in self.flat_buffers():
+            mv = self._state.get(master.data_ptr())
+            flat.append(None if mv is None else {"exp_avg": mv[0].detach().cpu(), "exp_avg_sq": mv[1].detach().cpu()})
+        return {"step": self.step_count, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
+                "flat": flat}
+
+    def load_state_dict(self, sd):
+        bufs = self.flat_buffers()
+        if len(sd["flat"]) != len(bufs):
+            raise ValueError("optimizer state does not match this model's flat buffers")
+        self.step_count, self.lr, self.betas, self.eps, self.wd = sd["step"], sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+        for (master, _, _), st in zip(bufs, sd["flat"]):
+            if st is None:
+                self._state.pop(master.data_ptr(), None)
+                continue
+            if st["exp_avg"].numel() != master.numel():
+                raise ValueError("optimizer state does not match this model's flat buffers")
+            self._state[master.data_ptr()] = (st["exp_avg"].to(master.device, torch.float32).clone(),
+                                              st["exp_avg_sq"].to(master.device, torch.float32).clone())

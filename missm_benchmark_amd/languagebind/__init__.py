@@ -6,15 +6,17 @@
 ``modality_scale`` dict, ``modality_config``) and ``forward(inputs) -> {modality: [B, projection_dim]}``.
 
 Differences that are build decisions (SURVEY.md sections 0.2, 8b):
-  * checkpoints cannot be fetched by NAME here (no network): ``from_pretrained`` resolves ``<cache_dir>/<name>`` or a
-    local path holding ``config.json`` + a state dict; when nothing is found the tower is built from the synthetic
-    ViT-B/16-class config below with a seeded init (what the benchmark uses) - pass ``configs=`` to override;
+  * checkpoints cannot be fetched by NAME here (no network): ``from_pretrained`` resolves a local path, ``<cache_dir>/<name>``
+    or the hub cache layout holding ``config.json`` + a state dict and fails loudly otherwise (like the reference); the
+    synthetic ViT-B/16-class config below with a seeded init (what the benchmark uses) is built on request only:
+    ``configs=`` or ``allow_synthetic=True``;
   * towers run on HIP kernels in ``compute_dtype`` (bf16 default, fp32 for parity) - see ``towers.ClipTower``;
   * image/video/audio preprocessing and the BPE tokenizer are outside this path.
 """
 from __future__ import annotations
 
 import json
+import math
 import os
 from dataclasses import asdict
 from typing import Dict, Optional
@@ -103,29 +105,55 @@ class LanguageBindModel(nn.Module):
         self.logit_scale = nn.Parameter(torch.tensor(float(logit_scale_init_value)))
 
     @classmethod
-    def from_pretrained(cls, pretrained_model_name_or_path: str, cache_dir: Optional[str] = None, **kw):
-        """Local-only resolution (there is no network): a directory with ``config.json`` and ``pytorch_model.bin`` /
-        ``model.pt``.  Falls back to the synthetic seeded model when the checkpoint is not on disk."""
-        for root in (pretrained_model_name_or_path, os.path.join(cache_dir or ".", pretrained_model_name_or_path)):
-            cfg_path = os.path.join(root, "config.json")
-            if os.path.isdir(root) and os.path.exists(cfg_path):
-                raw = json.load(open(cfg_path))
-                vc = TowerConfig(kind="vision", **{k: v for k, v in raw.get("vision_config", {}).items() if k in TowerConfig.__dataclass_fields__ and k != "kind"})
-                tc = TowerConfig(kind="text", **{k: v for k, v in raw.get("text_config", {}).items() if k in TowerConfig.__dataclass_fields__ and k != "kind"})
-                kw.pop("text_config", None)
-                kw.pop("projection_dim", None)
-                model = cls(vc, tc, raw.get("projection_dim", PROJECTION_DIM), raw.get("logit_scale_init_value", LOGIT_SCALE_INIT), **kw)
-                for fn in ("pytorch_model.bin", "model.pt", "model.pth"):
-                    p = os.path.join(root, fn)
-                    if os.path.exists(p):
-                        sd = torch.load(p, map_location="cpu")
-                        if any(".lora_A." in k for k in sd):
-                            vraw = raw.get("vision_config", {})
-                            sd = merge_lora_state_dict(sd, int(vraw.get("lora_r", 2)), float(vraw.get("lora_alpha", 16)))
-                        model.load_state_dict(sd, strict=False)
-                        break
-                return model
-        return cls(**kw)
+    def resolve_checkpoint_dir(cls, pretrained_model_name_or_path: str, cache_dir: Optional[str] = None) -> Optional[str]:
+        """Local-only resolution (there is no network): the path itself, ``<cache_dir>/<name>``, or the Hugging Face cache
+        layout ``<cache_dir>/models--<org>--<name>/snapshots/<rev>/`` - whichever holds a ``config.json``."""
+        name = pretrained_model_name_or_path
+        roots = [name, os.path.join(cache_dir or ".", name)]
+        hub = os.path.join(cache_dir or ".", "models--" + name.replace("/", "--"), "snapshots")
+        if os.path.isdir(hub):
+            roots += sorted(os.path.join(hub, r) for r in os.listdir(hub))
+        for root in roots:
+            if os.path.isdir(root) and os.path.exists(os.path.join(root, "config.json")):
+                return root
+        return None
+
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path: str, cache_dir: Optional[str] = None, *, allow_synthetic: bool = False,
+                        **kw):
+        """A directory with ``config.json`` and ``pytorch_model.bin`` / ``model.pt`` / ``model.pth`` (see
+        ``resolve_checkpoint_dir``).  Like the reference (languagebind/__init__.py:63-64) this FAILS when the checkpoint
+        cannot be found or is incomplete; a seeded synthetic model is built only on request (``allow_synthetic=True``, or
+        ``LanguageBind(configs=...)``)."""
+        root = cls.resolve_checkpoint_dir(pretrained_model_name_or_path, cache_dir)
+        if root is None:
+            if allow_synthetic:
+                return cls(**kw)
+            raise FileNotFoundError(f"checkpoint {pretrained_model_name_or_path!r} not found (looked in it, under cache_dir="
+                                    f"{cache_dir!r} and in its hub layout); there is no network here - pass a local directory, "
+                                    "LanguageBind(configs=...) or allow_synthetic=True for seeded random towers")
+        raw = json.load(open(os.path.join(root, "config.json")))
+        fields = TowerConfig.__dataclass_fields__
+        vc = TowerConfig(kind="vision", **{k: v for k, v in raw.get("vision_config", {}).items() if k in fields and k != "kind"})
+        tc = TowerConfig(kind="text", **{k: v for k, v in raw.get("text_config", {}).items() if k in fields and k != "kind"})
+        kw.pop("text_config", None)
+        kw.pop("projection_dim", None)
+        model = cls(vc, tc, raw.get("projection_dim", PROJECTION_DIM), raw.get("logit_scale_init_value", LOGIT_SCALE_INIT), **kw)
+        files = [os.path.join(root, fn) for fn in ("pytorch_model.bin", "model.pt", "model.pth") if os.path.exists(os.path.join(root, fn))]
+        if not files:
+            raise FileNotFoundError(f"{root} holds a config.json but no pytorch_model.bin / model.pt / model.pth")
+        sd = torch.load(files[0], map_location="cpu")
+        if any(".lora_A." in k for k in sd):
+            vraw = raw.get("vision_config", {})
+            sd = merge_lora_state_dict(sd, int(vraw.get("lora_r", 2)), float(vraw.get("lora_alpha", 16)))
+        sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}     # non-persistent buffers in newer layouts
+        res = model.load_state_dict(sd, strict=False)
+        has_text = hasattr(model, "text_model")
+        bad = [k for k in res.unexpected_keys if has_text or not k.startswith(("text_model.", "text_projection."))]
+        if res.missing_keys or bad:
+            raise KeyError(f"{files[0]} does not match the model built from {root}/config.json: missing {res.missing_keys[:8]}"
+                           f"{' ...' if len(res.missing_keys) > 8 else ''}, unexpected {bad[:8]}{' ...' if len(bad) > 8 else ''}")
+        return model
 
 
 def _model_class(modality: str):
@@ -164,11 +192,12 @@ _STREAM_PRIO = {k: int(v) for k, v in (kv.split("=") for kv in _os.environ.get("
 class LanguageBind(nn.Module):
     def __init__(self, clip_type, use_temp=True, cache_dir="./cache_dir", *, configs: Optional[Dict[str, TowerConfig]] = None,
                  text_config: Optional[TowerConfig] = None, projection_dim: int = PROJECTION_DIM,
-                 compute_dtype: torch.dtype = torch.bfloat16, seed: int = 0):
+                 compute_dtype: torch.dtype = torch.bfloat16, seed: int = 0, allow_synthetic: bool = False):
         super().__init__()
         self.use_temp = use_temp
         self.parallel_streams = True
         self._streams = {}
+        self._scale_cache = {}
         encoders, projs = {}, {}
         self.modality_scale = {}   # plain dict on purpose: un-registered in the reference too (languagebind/__init__.py:60,67)
         self.modality_config = {}
@@ -181,7 +210,7 @@ class LanguageBind(nn.Module):
                 model = model_dict[k](configs[k], text_config, projection_dim, **kw)
             else:
                 model = model_dict[k].from_pretrained(f"LanguageBind/{v}", cache_dir=cache_dir, text_config=text_config,
-                                                      projection_dim=projection_dim, **kw)
+                                                      projection_dim=projection_dim, allow_synthetic=allow_synthetic, **kw)
             encoders[k] = model.vision_model
             projs[k] = model.visual_projection
             self.modality_scale[k] = model.logit_scale
@@ -202,7 +231,13 @@ class LanguageBind(nn.Module):
         emb = self.modality_proj[key](pooled)
         scale = 1.0
         if self.use_temp and key != "language":
-            scale = float(self.modality_scale[key].detach().exp())
+            # exp(logit_scale) is a launch argument: read the (un-registered, normally CPU-resident) parameter only when it
+            # changed - on a GPU-resident one this would otherwise be a device-to-host stall per tower per forward
+            ls = self.modality_scale[key]
+            cached = self._scale_cache.get(key)
+            if cached is None or cached[0] != ls._version or cached[1] is not ls:
+                cached = self._scale_cache[key] = (ls._version, ls, math.exp(float(ls.detach())))
+            scale = cached[2]
         return hnn.l2norm_scale(emb, scale)
 
     def forward(self, inputs):

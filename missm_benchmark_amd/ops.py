@@ -229,16 +229,26 @@ def embed_assemble(patches, cls, pos, x, N, S, d):
     return x
 
 
+def _i64(t, what: str):
+    """index tensors cross the C ABI as ``const long*``: anything else would be reinterpreted, not converted"""
+    if t is not None and (t.dtype != torch.int64 or not t.is_contiguous()):
+        raise _lib.MissmError(f"{what} must be a contiguous int64 tensor (got {t.dtype})")
+    return t
+
+
 def token_embed_fwd(ids, tok, pos, h, B, S, d):
-    _lib.call("missm_token_embed_fwd", ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), h.data_ptr(), B, S, d, _s())
+    _i64(ids, "token_embed_fwd: input_ids")
+    _lib.call("missm_token_embed_fwd", ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), h.data_ptr(), B, S, d, tok.shape[0], _s())
     return h
 
 
 def token_embed_bwd(ids, dh, dtok, dpos, B, S, d):
-    _lib.call("missm_token_embed_bwd", ids.data_ptr(), dh.data_ptr(), dtok.data_ptr(), dpos.data_ptr(), B, S, d, _s())
+    _i64(ids, "token_embed_bwd: input_ids")
+    _lib.call("missm_token_embed_bwd", ids.data_ptr(), dh.data_ptr(), dtok.data_ptr(), dpos.data_ptr(), B, S, d, dtok.shape[0], _s())
 
 
 def argmax_rows(ids, out, B, S):
+    _i64(ids, "argmax_rows: input_ids")
     _lib.call("missm_argmax_rows", ids.data_ptr(), out.data_ptr(), B, S, _s())
     return out
 
@@ -248,6 +258,7 @@ def masked_copy_block(dst, src, row_code, code):
     B, W = src.shape
     if dst.shape != src.shape or dst.stride(1) != 1 or src.stride(1) != 1:
         raise _lib.MissmError("masked_copy_block: bad layout")
+    _i64(row_code, "masked_copy_block: row codes")
     _lib.call("missm_masked_copy_block", dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), B, W, _p(row_code), int(code), _s())
 
 
@@ -265,6 +276,7 @@ def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, x_sub=
     O = w.shape[0]
     if y.shape[0] < B or y.shape[1] != O or y.stride(1) != 1 or not x.is_contiguous() or not w.is_contiguous():
         raise _lib.MissmError("small_linear_fwd: bad operand layout")
+    _i64(row_code, "small_linear_fwd: row codes (missing_index)")
     _lib.call("missm_small_linear_fwd", x.data_ptr(), w.data_ptr(), _p(bias), y.data_ptr(), B, I, O, y.stride(0), int(relu),
               _p(row_code), int(code), _p(x_sub), int(select), float(alpha), int(accumulate), _s())
     return y
@@ -272,12 +284,14 @@ def small_linear_fwd(x, w, bias, y, *, relu=False, row_code=None, code=0, x_sub=
 
 def gate_fwd(d, pre, y, *, row_code=None, code=0, accumulate=False):
     B, F = pre.shape
+    _i64(row_code, "gate_fwd: row codes (missing_index)")
     _lib.call("missm_gate_fwd", d.data_ptr(), d.stride(0), pre.data_ptr(), y.data_ptr(), B, F, _p(row_code), int(code), int(accumulate), _s())
     return y
 
 
 def gate_bwd(dy, d, pre, dd, dpre, *, row_code=None, code=0, accumulate_dd=False):
     B, F = pre.shape
+    _i64(row_code, "gate_bwd: row codes (missing_index)")
     _lib.call("missm_gate_bwd", dy.data_ptr(), d.data_ptr(), d.stride(0), pre.data_ptr(), dd.data_ptr(), dd.stride(0), dpre.data_ptr(), B, F,
               _p(row_code), int(code), int(accumulate_dd), _s())
 
@@ -288,6 +302,7 @@ def small_linear_bwd(dy, x, w, dx, dw, dbias, *, relu_y=None, row_code=None, cod
     O = w.shape[0]
     if dy.shape[1] != O or dy.stride(1) != 1:
         raise _lib.MissmError("small_linear_bwd: bad dy layout")
+    _i64(row_code, "small_linear_bwd: row codes (missing_index)")
     _lib.call("missm_small_linear_bwd", dy.data_ptr(), dy.stride(0), x.data_ptr(), w.data_ptr(), _p(relu_y), _p(dx), _p(dw), _p(dbias),
               B, I, O, _p(row_code), int(code), _p(x_sub), int(select), float(alpha), int(accumulate_dx), int(accumulate_dw), _s())
 
@@ -303,6 +318,9 @@ def l2norm_scale_bwd(dy, x, dx, scale):
 
 
 def cross_entropy(logits, labels, loss, dlogits):
+    _i64(labels, "cross_entropy: labels")
+    if labels.numel() != logits.shape[0]:
+        raise _lib.MissmError("cross_entropy: one label per row of logits")
     _lib.call("missm_cross_entropy", logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dlogits), logits.shape[0],
               logits.shape[1], _s())
     return loss

@@ -81,8 +81,11 @@ class ClipTower(nn.Module):
         self.compute_dtype = compute_dtype
         d, f = c.hidden_size, c.intermediate_size
         blocks: List[Block] = []
+        patch_block = None
         if c.kind == "vision":
-            blocks.append(Block([("embeddings.patch_embedding.weight", (d, c.num_channels, c.patch_size, c.patch_size))], "mat"))
+            # (appended AFTER the layers' matrices: the backward finishes with the embeddings, so the last gradient bucket -
+            #  patch embedding + every vector parameter - is one contiguous range of the flat buffer)
+            patch_block = Block([("embeddings.patch_embedding.weight", (d, c.num_channels, c.patch_size, c.patch_size))], "mat")
             blocks.append(Block([("embeddings.class_embedding", (d,)), ("embeddings.position_embedding.weight", (c.seq_len, d)),
                                  ("pre_layrnorm.weight", (d,)), ("pre_layrnorm.bias", (d,))], "vec"))
         else:
@@ -114,19 +117,28 @@ class ClipTower(nn.Module):
             blocks.append(Block(vec, "vec"))
         tail = "post_layernorm" if c.kind == "vision" else "final_layer_norm"
         blocks.append(Block([(f"{tail}.weight", (d,)), (f"{tail}.bias", (d,))], "vec"))
-        if c.kind == "vision":
-            self._mat_blocks["patch"] = blocks[0]
+        if patch_block is not None:
+            blocks.append(patch_block)
+            self._mat_blocks["patch"] = patch_block
         self._store = FlatStore(blocks)
+        # gradient buckets (engine.TrainEngine, N > 1 GPUs): flat ranges that become final as the backward walks the layers
+        # 11 -> 0; `bucket_layers` consecutive layers per message, then [patch embedding | all vector parameters] at the end
+        self.bucket_layers = 3
+        self._bucket_hook = None
         self._param_names = list(self._store.index.keys())
         for name in self._param_names:
             attach(self, name, nn.Parameter(self._store.view(name)))
         n_pos = c.seq_len
         self.embeddings.register_buffer("position_ids", torch.arange(n_pos).expand((1, -1)).clone(), persistent=False)
         self._anchor = torch.zeros((), requires_grad=True)
+        self._plist = [self.get_parameter(n) for n in self._param_names]
         self._shadow = {}
         self._shadow_version = None
+        # load_state_dict writes through the parameters: belt and braces next to the version key below
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.mark_dirty())
         self._lp = None
         self._grad_fresh = False     # True between a backward of this tower and the optimizer step that consumes it
+        self._accumulate = False     # set per backward: add to (instead of overwrite) the parameter gradients
         self._post_backward = None
         self._grad_cache = None   # set by engine.TrainEngine: called once the last backward kernel is enqueued
         self.reset_parameters(0 if seed is None else seed)
@@ -172,7 +184,9 @@ class ClipTower(nn.Module):
             p = self.get_parameter(name)
             p.data = self._store.view(name)
             p.grad = None
+        self._plist = [self.get_parameter(n) for n in self._param_names]
         self._grad_cache = None
+        self._grad_fresh = False
         self._shadow.clear()
         self._shadow_version = None
         self._lp = None
@@ -198,6 +212,16 @@ class ClipTower(nn.Module):
     def mark_dirty(self):
         self._shadow_version = None
 
+    def _version_key(self) -> int:
+        """Changes whenever the fp32 master weights are written through torch: in place on the flat buffer, or through any
+        parameter view.  ``p.data = view`` (what ``_rebind`` does on a device move, keeping the Parameter objects that
+        optimizers already hold) gives every Parameter its OWN version counter, so the master's counter alone misses
+        ``load_state_dict`` / ``torch.optim`` steps / ``p.mul_()`` after a ``.cuda()``: sum them all (~200 reads, a few us)."""
+        v = self._store.master._version
+        for p in self._plist:
+            v += p._version
+        return v
+
     def flat_master(self) -> torch.Tensor:
         return self._store.master
 
@@ -220,7 +244,7 @@ class ClipTower(nn.Module):
                 entries.append((src, None if T == torch.float32 else w, wt))
             self._cast_table, self._cast_tiles = ops.build_cast_table(entries, st.master.device)
         ops.cast_weights_batched(self._cast_table, self._cast_tiles, ops.F32 if T == torch.float32 else ops.BF16)
-        self._shadow_version = st.master._version
+        self._shadow_version = self._version_key()
 
     # ---- optimizer step fused with the shadow refresh (engine.TrainEngine) ----------------------------------------
     def vec_start(self) -> int:
@@ -229,7 +253,7 @@ class ClipTower(nn.Module):
     def fused_update_ready(self) -> bool:
         """shadows exist and are current: the weight matrices may be updated through the cast-tile table"""
         st = self._store
-        return bool(self._shadow) and self._shadow_version == st.master._version and st.master.is_cuda
+        return bool(self._shadow) and st.master.is_cuda and self._shadow_version == self._version_key()
 
     def adam_and_refresh(self, grad, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
         st = self._store
@@ -242,7 +266,7 @@ class ClipTower(nn.Module):
         st = self._store
         if not st.master.is_cuda:
             raise _lib.MissmError("ClipTower runs only on an MI355X (move the module to cuda); there is no CPU fallback")
-        if self._shadow_version != st.master._version or not self._shadow:
+        if not self._shadow or self._shadow_version != self._version_key():
             self._refresh_shadows()
         if self._lp is None:
             self._build_layer_params()
@@ -284,6 +308,28 @@ class ClipTower(nn.Module):
 
     def _w(self, key):
         return self._shadow[key]
+
+    def layer_mat_range(self, lo_layer: int, hi_layer: int):
+        """[start, end) of the flat buffer covering the weight matrices of layers lo_layer..hi_layer (inclusive)"""
+        first = "tqkv" if self.config.add_time_attn else "qkv"
+        a = self._mat_blocks[f"encoder.layers.{lo_layer}.{first}"]
+        if hi_layer + 1 < self.config.num_hidden_layers:
+            end = self._mat_blocks[f"encoder.layers.{hi_layer + 1}.{first}"].offset
+        else:
+            end = self._mat_blocks["patch"].offset if "patch" in self._mat_blocks else self._store.vec_start
+        return a.offset, end
+
+    def bucket_ranges(self):
+        """the flat ranges in the order the backward hands them out (layers top-down in groups of `bucket_layers`, then the
+        tail); together they cover the gradient buffer exactly once"""
+        L, k = self.config.num_hidden_layers, self.bucket_layers
+        out = [self.layer_mat_range(i, min(i + k, L) - 1) for i in reversed(range(L)) if i % k == 0]
+        return out + [self.tail_range()]
+
+    def tail_range(self):
+        """[start, end): patch-embedding matrix (vision) + every vector parameter - final only when the backward has ended"""
+        start = self._mat_blocks["patch"].offset if "patch" in self._mat_blocks else self._store.vec_start
+        return start, self._store.total
 
     # ------------------------------------------------------------------ public forward (reference signature)
     def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, *,
@@ -435,9 +481,10 @@ class ClipTower(nn.Module):
     # ------------------------------------------------------------------ backward implementation
     def _linear_bwd(self, dy, x, wt, g_w, g_b, rows, dx_out=None, act=ops.ACT_NONE, aux_in=None):
         """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result
-        STORED into the fp32 gradient); db += colsum(dy) riding in the same GEMM (zeroed tail of the gradient buffer);
-        dx = dy W through the transposed compute-dtype shadow (NT form, vector epilogue)."""
-        ops.gemm(dy, x, g_w, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_b)
+        STORED into the fp32 gradient - or ADDED to it when this backward accumulates, see _backward_impl); db += colsum(dy)
+        riding in the same GEMM (tail of the gradient buffer); dx = dy W through the transposed compute-dtype shadow (NT
+        form, vector epilogue)."""
+        ops.gemm(dy, x, g_w, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_b, accumulate=self._accumulate)
         if dx_out is not None:
             ops.gemm(dy, wt, dx_out, act=act, aux_in=aux_in, M=rows)
         return dx_out
@@ -448,7 +495,15 @@ class ClipTower(nn.Module):
         d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
         hd = d // H
         B, Tf, N, S, rows = s.geom
-        st.zero_accumulated()
+        # torch.autograd semantics for .grad: a backward ADDS to gradients that have not been consumed yet - a second
+        # micro-batch, the reference's teacher and student sharing one encoder, a tower called twice in a step.  "Consumed"
+        # = the engine's optimizer step ran (_grad_fresh cleared) or zero_grad(set_to_none=True) detached the views; after
+        # zero_grad(set_to_none=False) the buffers hold zeros, and adding to them is the same as storing.  In "autograd"
+        # gradient mode the values are handed to autograd, which does its own accumulation.
+        self._accumulate = bool(self._grad_fresh and _GRAD_MODE == "direct" and self._plist[0].grad is not None
+                                and st.grad is not None and self._plist[0].grad.data_ptr() == st.gview(self._param_names[0]).data_ptr())
+        if not self._accumulate:
+            st.zero_accumulated()
         g = st.gview
         f32 = dict(device=dev, dtype=torch.float32)
         h_fin, mp, rp, eot, mf, rf = s.pool
@@ -501,6 +556,10 @@ class ClipTower(nn.Module):
                 if Tf != 1:
                     ops.colsum(dh, L.g_temb, div=S, mod=Tf, R=rows)
             s.layers[i] = None
+            if self._bucket_hook is not None and i % self.bucket_layers == 0:
+                # the weight-matrix gradients of layers i .. i+bucket_layers-1 are final (their kernels are enqueued): hand the
+                # range to the engine, whose all-reduce then travels while the layers below are still differentiating
+                self._bucket_hook(self, *self.layer_mat_range(i, min(i + self.bucket_layers, c.num_hidden_layers) - 1))
         # ---- embeddings
         if c.kind == "vision":
             U, x0, m0, r0 = s.emb

@@ -170,7 +170,7 @@ def train(args, train_loader: Iterable, valid_loader: Iterable, output_dims: int
         encoder_model = LanguageBind(clip_type=clip_type, cache_dir="./cache_dir", compute_dtype=compute_dtype, seed=args.seed)
     model = finetune_model(args, output_dims, encoder_model).to(device)
     criterion = get_criterion(args)
-    engine = TrainEngine(model, lr=args.learning_rate, weight_decay=args.weight_decay)
+    engine = TrainEngine(model, lr=args.learning_rate, weight_decay=args.weight_decay, eager_step=True)   # this loop: one backward per step
     best, best_epoch, patience, lr_bad = 0.0, 0, 0, 0
     for epoch in range(args.num_epochs):
         model.train()
@@ -195,7 +195,7 @@ def train(args, train_loader: Iterable, valid_loader: Iterable, output_dims: int
             best, best_epoch, patience, lr_bad = val["accuracy"], epoch, 0, 0
             if local_rank == 0:
                 sd = {"module." + k: v.detach().cpu() for k, v in model.state_dict().items()}   # DDP-prefixed like :302
-                torch.save({"epoch": epoch, "model_state_dict": sd, "optimizer_state_dict": {"step": engine.step_count},
+                torch.save({"epoch": epoch, "model_state_dict": sd, "optimizer_state_dict": engine.state_dict(),
                             "val_metrics": val, "args": vars(args)}, os.path.join(save_path, "best_model.pth"))
         else:
             patience += 1

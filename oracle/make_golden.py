@@ -85,7 +85,7 @@ def vision_fixture(name, modality, cfg: O.VisionCfg, batch, seed_w, seed_x, stor
     print(f"{name}: ref-vs-oracle last {float((h - last).abs().max()):.2e} pooled {float((p - pooled).abs().max()):.2e}")
 
 
-def text_fixture(name, cfg: O.TextCfg, batch, seed_w, seed_x, grad_names=()):
+def text_fixture(name, cfg: O.TextCfg, batch, seed_w, seed_x, grad_names=(), compact=False):
     from transformers import CLIPTextConfig, CLIPTextModel
     tc = CLIPTextConfig(vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                         num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
@@ -120,6 +120,16 @@ def text_fixture(name, cfg: O.TextCfg, batch, seed_w, seed_x, grad_names=()):
         hr = rt.final_layer_norm(rt.encoder(inputs_embeds=h0, attention_mask=merged, return_dict=False)[0])
         pr = hr[torch.arange(batch), ids.to(torch.int).argmax(-1)]
     fix["pooled_ref_encoder"] = pr
+    if compact:  # full-size tower: weights by recipe (seed_w), slices of the big tensors only
+        fix.pop("params")
+        fix["last_hidden_slice"] = fix.pop("last_hidden_state")[:, :, :64].clone()
+        g = fix.get("grads", {})
+        tok = "embeddings.token_embedding.weight"
+        if tok in g:   # rows that actually receive gradient: the ids of the batch (BOS, EOS, a few words)
+            rows = torch.unique(ids)[:48]
+            fix["grad_rows"] = {tok: (rows, g[tok][rows][:, :64].clone())}
+            del g[tok]
+        fix["grads"] = {k: (v[:64, :64] if v.dim() == 2 else v[:64]).clone() for k, v in g.items()}
     torch.save(fix, os.path.join(OUT, name + ".pt"))
     with torch.no_grad():
         h, p = O.text_tower(ids, mask, params, cfg)
@@ -274,6 +284,10 @@ def main():
                                         num_attention_heads=2, max_position_embeddings=16), batch=5, seed_w=7, seed_x=8,
                  grad_names=("embeddings.token_embedding.weight", "embeddings.position_embedding.weight",
                              f"{lname}.self_attn.q_proj.weight", f"{lname}.mlp.fc2.weight", "final_layer_norm.weight"))
+    # BASELINE.json configs[1]'s text side at full size: d=768, 12 layers, 12 heads (head_dim 64), S=77, vocab 49408, causal + padding
+    run(text_fixture, "text_full", O.TextCfg(), batch=4, seed_w=9, seed_x=10, compact=True,
+        grad_names=("embeddings.token_embedding.weight", "embeddings.position_embedding.weight", f"{lname}.self_attn.q_proj.weight",
+                    "encoder.layers.11.mlp.fc2.weight", "encoder.layers.5.self_attn.k_proj.weight", "final_layer_norm.weight"))
     run(fusion_fixture, "fusion_sum", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5, seed=11)
     run(fusion_fixture, "fusion_concat", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5, seed=21,
                    fusion_type="concat")

@@ -51,7 +51,7 @@ def test_error_channel_without_gpu(lib):
     assert rc == -1
     assert b"gemm" in lib.missm_last_error()
     from missm_benchmark_amd import _lib as L
-    assert lib.missm_abi_version() == L.ABI_VERSION == 2
+    assert lib.missm_abi_version() == L.ABI_VERSION >= 3
     assert lib.missm_device_count() >= 0
 
 

@@ -1,0 +1,326 @@
+"""BASELINE.json configs[1] and configs[3] at full tower size on the GPU, through the drop-in modules and the C ABI.
+
+  * the full-size text tower (d=768, 12 layers, head_dim 64 -> the MFMA causal + key-mask attention kernel, S=77, vocab 49408,
+    atomic scatter into the 49408 x 768 embedding gradient, EOT-gather LayerNorm) against the fixture captured from stock
+    transformers + the reference's encoder code (tests/golden/text_full.pt) - fp32 instantiation 1e-3, bf16 by its own bars;
+  * configs[1]: image + text `sum` fusion step against the CPU oracle at B = 4; at B = 32 through size-independent properties;
+  * configs[3]: five modalities with 30 % mixed missing codes (incl. this build's codes 5 / 6) at B = 32: a missing
+    (sample, modality) contributes exactly zero to that tower's embedding gradient; oracle agreement on 4 of the samples;
+  * semantics the reference relies on: weights changed through torch (load_state_dict, torch.optim) reach the kernels,
+    `.grad` accumulates over backward calls like autograd's.
+"""
+import os
+import types
+
+import pytest
+import torch
+
+import missm_oracle as O
+from conftest import load_golden
+from test_towers_gpu import TOL32, TOLBF, grad_ok, make_tower, rel
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import missm_benchmark_amd as M
+    lb, base = M.install()
+    from missm_benchmark_amd import towers
+    torch.set_num_threads(max(1, min(16, len(os.sched_getaffinity(0)))))
+    return types.SimpleNamespace(lb=lb, base=base, towers=towers)
+
+
+def _sliced(mine, ref):
+    if mine.shape != ref.shape:
+        mine = mine[:64, :64] if mine.dim() == 2 else mine[:64]
+    return mine
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOLBF)])
+def test_full_size_text_tower_vs_reference_fixture(pkg, dtype, tol):
+    fix = load_golden("text_full")
+    cfg = O.TextCfg(**fix["cfg"])
+    params = O.init_tower_params(cfg, fix["seed_w"], kind="text")
+    tower = make_tower(pkg, fix["cfg"], "text", params, dtype)
+    assert tower.config.hidden_size // tower.config.num_attention_heads == 64      # the MFMA attention path
+    ids, mask = fix["input_ids"].cuda(), fix["attention_mask"].cuda()
+    last, pooled = tower(input_ids=ids, attention_mask=mask)
+    assert rel(pooled, fix["pooled"]) < tol
+    assert rel(pooled, fix["pooled_ref_encoder"]) < tol
+    valid = fix["attention_mask"].bool()
+    assert rel(last.cpu()[:, :, :64][valid], fix["last_hidden_slice"][valid]) < tol
+    (pooled * fix["cot_pooled"].cuda()).sum().backward()
+    gtol = tol * 3
+    for k, g in fix["grads"].items():
+        assert grad_ok(k, _sliced(tower.get_parameter(k).grad, g), g, gtol, dtype), k
+    for k, (rows, g) in fix["grad_rows"].items():      # the embedding rows that received a scattered gradient
+        mine = tower.get_parameter(k).grad[rows.cuda()][:, :64]
+        assert grad_ok(k, mine, g, gtol, dtype), k
+    # rows of the 49408-row table that no token of the batch addresses stay exactly zero
+    used = torch.zeros(cfg.vocab_size, dtype=torch.bool)
+    used[fix["input_ids"].flatten()] = True
+    tg = tower.get_parameter("embeddings.token_embedding.weight").grad
+    assert float(tg[(~used).cuda()].abs().max()) == 0.0
+
+
+def _two_modality_model(pkg, dtype, seed=3):
+    T = pkg.towers.TowerConfig
+    enc = pkg.lb.LanguageBind({"image": "LanguageBind_Image"}, configs={"image": T(kind="vision")}, text_config=T(kind="text"),
+                              compute_dtype=dtype, seed=seed)
+    args = types.SimpleNamespace(modality_types=["language", "image"], feature_dims=768, fusion_dim=256, dropout_prob=0.0,
+                                 fusion_type="sum")
+    torch.manual_seed(0)
+    return pkg.base.finetune_model(args, 8, enc), args
+
+
+def _oracle_parts(sd, mods):
+    tp, cfgs = {}, {}
+    for m in mods:
+        pre = f"encoder.modality_encoder.{m}."
+        tp[m] = {k[len(pre):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+        cfgs[m] = O.TextCfg() if m == "language" else O.VisionCfg(add_time_attn=(m == "video"), num_frames=8 if m == "video" else 1)
+    proj = {m: sd[f"encoder.modality_proj.{m}.weight"].clone().requires_grad_(True) for m in mods}
+    scales = {m: torch.tensor(2.6592) for m in mods if m != "language"}
+    fp = {k[len("fusion."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("fusion.")}
+    return tp, cfgs, proj, scales, fp
+
+
+def _config1_batch(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    ids, mask = O.synth_text_batch(B, 77, seed + 1)
+    data = {"language": {"input_ids": ids, "attention_mask": mask},
+            "image": {"pixel_values": torch.randn(B, 3, 224, 224, generator=g)}}
+    return data, torch.randint(0, 8, (B,), generator=g)
+
+
+def _to_gpu(data):
+    return {m: {k: v.cuda() for k, v in d.items()} for m, d in data.items()}
+
+
+def test_config1_image_text_step_vs_oracle(pkg):
+    """configs[1] (image + text, `sum` fusion, C = 8) - forward, CE, full backward at B = 4 against the CPU oracle, both
+    instantiations; one missing-language and one missing-image sample."""
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    model, args = _two_modality_model(pkg, torch.float32)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    tp, cfgs, proj, scales, fp = _oracle_parts(sd, ["language", "image"])
+    data, labels = _config1_batch(4, 21)
+    missing = torch.tensor([0, 1, 4, 0])
+    ologits, _ = O.finetune_forward(data, missing, tp, cfgs, proj, scales, fp, args.modality_types)
+    oloss = O.cross_entropy(ologits, labels)
+    oloss.backward()
+    og = {"encoder.modality_encoder.language.embeddings.token_embedding.weight": tp["language"]["embeddings.token_embedding.weight"].grad,
+          "encoder.modality_encoder.language.encoder.layers.0.self_attn.q_proj.weight": tp["language"]["encoder.layers.0.self_attn.q_proj.weight"].grad,
+          "encoder.modality_encoder.language.encoder.layers.11.mlp.fc1.weight": tp["language"]["encoder.layers.11.mlp.fc1.weight"].grad,
+          "encoder.modality_encoder.language.final_layer_norm.weight": tp["language"]["final_layer_norm.weight"].grad,
+          "encoder.modality_encoder.image.encoder.layers.6.self_attn.out_proj.weight": tp["image"]["encoder.layers.6.self_attn.out_proj.weight"].grad,
+          "encoder.modality_encoder.image.embeddings.patch_embedding.weight": tp["image"]["embeddings.patch_embedding.weight"].grad,
+          "encoder.modality_proj.language.weight": proj["language"].grad, "encoder.modality_proj.image.weight": proj["image"].grad,
+          "fusion.modal_proj.language.weight": fp["modal_proj.language.weight"].grad, "fusion.head.head.3.bias": fp["head.head.3.bias"].grad}
+    model = model.cuda()
+    gdata = _to_gpu(data)
+    for dtype, tol in ((torch.float32, TOL32), (torch.bfloat16, 5e-2)):
+        model.encoder.set_compute_dtype(dtype)
+        model.zero_grad(set_to_none=True)
+        logits = model(gdata, missing.cuda())
+        loss = HipCrossEntropyLoss()(logits, labels.cuda())
+        loss.backward()
+        assert rel(logits, ologits) < tol, dtype
+        assert abs(float(loss.detach()) - float(oloss.detach())) < tol * max(1.0, float(oloss.detach()))
+        for k, ref in og.items():
+            mine = model.get_parameter(k).grad
+            if "token_embedding" in k:          # compare the rows that carry gradient (a dense max over 38 M zeros says nothing)
+                rows = torch.unique(data["language"]["input_ids"])
+                mine, ref_ = mine[rows.cuda()], ref[rows]
+            else:
+                ref_ = ref
+            assert grad_ok(k, mine, ref_, tol * 4, dtype), (k, dtype)
+
+
+def test_config1_b32_properties(pkg):
+    """configs[1] at its full batch (B = 32, bf16): batch independence against the B = 4 run the oracle checked, linearity of the
+    backward in the loss scale, run-to-run bit-reproducibility of the GEMM weight gradients, zero gradient into untouched
+    embedding rows."""
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    model, args = _two_modality_model(pkg, torch.bfloat16)
+    model = model.cuda()
+    data, labels = _config1_batch(32, 40)
+    gdata = _to_gpu(data)
+    missing = torch.zeros(32, dtype=torch.int64)
+    missing[3], missing[17] = 1, 4
+    crit = HipCrossEntropyLoss()
+    logits = model(gdata, missing.cuda())
+    with torch.no_grad():
+        sub = {m: {k: v[:4] for k, v in d.items()} for m, d in gdata.items()}
+        l4 = model(sub, missing[:4].cuda())
+    assert rel(l4, logits[:4]) < 2e-3                               # samples do not see each other
+    names = ["encoder.modality_encoder.language.encoder.layers.0.self_attn.q_proj.weight",
+             "encoder.modality_encoder.language.encoder.layers.11.mlp.fc2.weight",
+             "encoder.modality_encoder.image.encoder.layers.3.mlp.fc1.weight"]
+    crit(logits, labels.cuda()).backward()
+    g1 = {k: model.get_parameter(k).grad.clone() for k in names}
+    tok1 = model.get_parameter("encoder.modality_encoder.language.embeddings.token_embedding.weight").grad.clone()
+    model.zero_grad(set_to_none=True)
+    (2.0 * crit(model(gdata, missing.cuda()), labels.cuda())).backward()
+    for k in names:
+        assert rel(model.get_parameter(k).grad, 2.0 * g1[k]) < 1e-3, k          # linear in the upstream gradient
+    g2 = {k: model.get_parameter(k).grad.clone() for k in names}
+    model.zero_grad(set_to_none=True)
+    (2.0 * crit(model(gdata, missing.cuda()), labels.cuda())).backward()
+    for k in names:
+        assert torch.equal(model.get_parameter(k).grad, g2[k]), k               # ordered split-K reduce: bit-reproducible
+    used = torch.zeros(49408, dtype=torch.bool)
+    used[data["language"]["input_ids"].flatten()] = True
+    assert float(tok1[(~used).cuda()].abs().max()) == 0.0 and float(tok1[used.cuda()].abs().max()) > 0.0
+
+
+def test_config3_mixed_missing_codes_b32(pkg):
+    """configs[3]: five modalities, B = 32, `synth_missing_index(32, mods, 0.3, 2025)` (the reference's 'mixed' recipe,
+    src/utils/generate_missing.py:21-38, incl. this build's codes 5 = depth / 6 = thermal), bf16 instantiation.
+    (a) every (sample, modality) whose code matches contributes exactly zero to that tower's embedding gradient, every other
+    one a non-zero gradient; (b) the logits of 4 samples (chosen to cover codes 5 and 6) agree with the CPU oracle, fp32
+    instantiation at 1e-3; (c) their gradients agree with the oracle's on the same 4-sample batch."""
+    from missm_benchmark_amd.data import synth_missing_index
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    mods = ["video", "image", "audio", "depth", "thermal"]
+    T = pkg.towers.TowerConfig
+    cfgs = {m: T(kind="vision", add_time_attn=(m == "video"), num_frames=8 if m == "video" else 1) for m in mods}
+    enc = pkg.lb.LanguageBind({m: f"LanguageBind_{m.capitalize()}" for m in mods}, configs=cfgs, compute_dtype=torch.bfloat16, seed=5)
+    args = types.SimpleNamespace(modality_types=mods, feature_dims=768, fusion_dim=256, dropout_prob=0.0, fusion_type="sum")
+    torch.manual_seed(0)
+    model = pkg.base.finetune_model(args, 8, enc)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    B = 32
+    missing = synth_missing_index(B, mods, 0.3, 2025)
+    codes = {m: pkg.base.missing_type_index[m] for m in mods}
+    assert int((missing != 0).sum()) == int(B * 0.3)
+    assert {5, 6} <= set(missing.tolist()), "the seeded draw must exercise the extension codes (depth 5 / thermal 6)"
+    g = torch.Generator().manual_seed(77)
+    data = {m: {"pixel_values": torch.randn(*((B, 3, 8, 224, 224) if m == "video" else (B, 3, 224, 224)), generator=g)} for m in mods}
+    labels = torch.randint(0, 8, (B,), generator=g)
+    gdata = _to_gpu(data)
+    emb = model.encoder(gdata)
+    for e in emb.values():
+        e.retain_grad()
+    logits = model.fusion(emb, missing.cuda())
+    HipCrossEntropyLoss()(logits, labels.cuda()).backward()
+    for m in mods:
+        ge = emb[m].grad
+        hit = (missing == codes[m]).cuda()
+        assert float(ge[hit].abs().max()) == 0.0 if bool(hit.any()) else True, m          # (a) exactly zero
+        assert bool((ge[~hit].abs().amax(dim=1) > 0).all()), m
+    assert all(model.get_parameter(f"encoder.modality_encoder.{m}.encoder.layers.0.mlp.fc1.weight").grad is not None for m in mods)
+    # (b) + (c): 4 samples covering codes 5 and 6, a present-everything sample and one more missing code
+    pick = [int((missing == 5).nonzero()[0]), int((missing == 6).nonzero()[0]), int((missing == 0).nonzero()[0])]
+    others = [i for i in range(B) if int(missing[i]) not in (0, 5, 6)]
+    pick.append(others[0] if others else int((missing == 0).nonzero()[1]))
+    idx = torch.tensor(pick)
+    tp, ocfg, proj, scales, fp = _oracle_parts(sd, mods)
+    sub = {m: {"pixel_values": data[m]["pixel_values"][idx]} for m in mods}
+    ologits, _ = O.finetune_forward(sub, missing[idx], tp, ocfg, proj, scales, fp, mods)
+    oloss = O.cross_entropy(ologits, labels[idx])
+    oloss.backward()
+    assert rel(logits[idx.cuda()], ologits) < 5e-2                      # the B = 32 bf16 run, batch-independent rows
+    model.encoder.set_compute_dtype(torch.float32)
+    model.zero_grad(set_to_none=True)
+    l4 = model(_to_gpu(sub), missing[idx].cuda())
+    loss4 = HipCrossEntropyLoss()(l4, labels[idx].cuda())
+    loss4.backward()
+    assert rel(l4, ologits) < TOL32
+    assert abs(float(loss4.detach()) - float(oloss.detach())) < TOL32 * max(1.0, float(oloss.detach()))
+    checks = {"encoder.modality_encoder.depth.encoder.layers.0.self_attn.q_proj.weight": tp["depth"]["encoder.layers.0.self_attn.q_proj.weight"],
+              "encoder.modality_encoder.thermal.encoder.layers.11.mlp.fc2.weight": tp["thermal"]["encoder.layers.11.mlp.fc2.weight"],
+              "encoder.modality_encoder.video.encoder.layers.4.temporal_attn.out_proj.weight": tp["video"]["encoder.layers.4.temporal_attn.out_proj.weight"],
+              "encoder.modality_proj.depth.weight": proj["depth"], "fusion.modal_proj.thermal.weight": fp["modal_proj.thermal.weight"],
+              "fusion.modal_proj.depth.bias": fp["modal_proj.depth.bias"]}
+    for k, ref in checks.items():
+        assert grad_ok(k, model.get_parameter(k).grad, ref.grad, TOL32 * 4, torch.float32), k
+
+
+def test_weights_changed_through_torch_reach_the_kernels(pkg):
+    """after `.cuda()` the parameters are re-pointed views; writes through them (load_state_dict, a
+    torch.optim step, p.mul_) must invalidate the bf16 weight copies the GEMMs read."""
+    fix = load_golden("vision_tiny")
+    x = fix["pixel_values"].cuda()
+    tower = make_tower(pkg, fix["cfg"], "vision", fix["params"], torch.bfloat16)
+    with torch.no_grad():
+        _, p0 = tower(x)                                           # builds the bf16 shadows
+    other = {k: v * 1.25 + 0.01 for k, v in fix["params"].items()}
+    tower.load_state_dict(other)
+    fresh = make_tower(pkg, fix["cfg"], "vision", other, torch.bfloat16)
+    with torch.no_grad():
+        _, p1 = tower(x)
+        _, pf = fresh(x)
+    assert torch.equal(p1, pf) and rel(p1, p0) > 1e-3              # the new weights are the ones that ran
+    # torch.optim on the parameters (autograd gradient mode hands gradients to autograd like any module)
+    pkg.towers.set_grad_mode("autograd")
+    try:
+        opt = torch.optim.SGD(tower.parameters(), lr=0.5)
+        _, p = tower(x)
+        p.square().sum().backward()
+        opt.step()
+        with torch.no_grad():
+            _, p2 = tower(x)
+        fresh2 = make_tower(pkg, fix["cfg"], "vision", {k: v.detach().cpu() for k, v in tower.state_dict().items()}, torch.bfloat16)
+        with torch.no_grad():
+            _, pf2 = fresh2(x)
+        assert torch.equal(p2, pf2) and rel(p2, p1) > 1e-4
+    finally:
+        pkg.towers.set_grad_mode("direct")
+    with torch.no_grad():
+        tower.get_parameter("encoder.layers.0.mlp.fc1.weight").mul_(1.5)
+        _, p3 = tower(x)
+    assert rel(p3, p2) > 1e-4
+
+
+def test_grad_accumulates_over_backwards_like_autograd(pkg):
+    """two backward calls before the gradients are consumed ADD (micro-batches, a tower called twice); zero_grad resets"""
+    fix = load_golden("video_tiny")
+    tower = make_tower(pkg, fix["cfg"], "vision", fix["params"], torch.float32)
+    x = fix["pixel_values"].cuda()
+    cot = fix["cot_pooled"].cuda()
+    names = [k for k in fix["grads"]]
+    _, p = tower(x)
+    (p * cot).sum().backward()
+    g1 = {k: tower.get_parameter(k).grad.clone() for k in names}
+    _, p = tower(x)
+    (p * (0.5 * cot)).sum().backward()                              # second micro-batch: accumulates
+    for k in names:
+        if k.endswith("k_proj.bias"):
+            continue
+        assert rel(tower.get_parameter(k).grad, 1.5 * g1[k]) < 1e-4, k
+    tower.zero_grad(set_to_none=True)
+    _, p = tower(x)
+    (p * cot).sum().backward()                                      # after zero_grad: a fresh gradient
+    for k in names:
+        if k.endswith("k_proj.bias"):
+            continue
+        assert rel(tower.get_parameter(k).grad, g1[k]) < 1e-5, k
+    tower.zero_grad(set_to_none=False)                              # zeroed in place: accumulating into zeros is the same
+    _, p = tower(x)
+    (p * cot).sum().backward()
+    for k in names:
+        if k.endswith("k_proj.bias"):
+            continue
+        assert rel(tower.get_parameter(k).grad, g1[k]) < 1e-5, k
+
+
+def test_eager_engine_rejects_second_backward(pkg):
+    from missm_benchmark_amd.engine import TrainEngine
+    fix = load_golden("vision_tiny")
+    tower = make_tower(pkg, fix["cfg"], "vision", fix["params"], torch.float32)
+    eng = TrainEngine(tower, lr=1e-3, eager_step=True)
+    x = fix["pixel_values"].cuda()
+    _, p = tower(x)
+    p.sum().backward()
+    _, p = tower(x)
+    with pytest.raises(RuntimeError, match="second backward"):
+        p.sum().backward()
+    eng.step()
+    _, p = tower(x)
+    p.sum().backward()                                              # a new step is fine again
+    eng.step()

@@ -1,5 +1,8 @@
 """Data-parallel engine on the GPU: 2 ranks (gloo, both on device 0 - RCCL refuses two ranks on one device) must
-(a) stay bit-identical to each other and (b) match one process training on the concatenated batch (1e-4)."""
+(a) stay bit-identical to each other, (b) match one process training on the concatenated batch (1e-4) and the CPU oracle's
+gradient of that batch (1e-3), and (c) give the same parameters on the path bench.py / train() actually run - bucketed
+all-reduce overlapped with the backward, Adam enqueued on the communication stream behind each tower's reduction
+(eager_step=True, overlap=True) - as on the plain path (reduce everything, then step)."""
 import os
 import sys
 import types
@@ -43,18 +46,23 @@ KEYS = ["encoder.modality_encoder.video.encoder.layers.0.temporal_attn.q_proj.we
         "fusion.head.head.3.weight", "encoder.modality_encoder.video.embeddings.position_embedding.weight"]
 
 
-def _train(model, batches, steps=2, lr=1e-3):
-    """returns (mean gradients of the first step as the optimizer sees them, parameters after `steps` steps)"""
+def _train(model, batches, steps=2, lr=1e-3, eager=False):
+    """returns (mean gradients of the first step as the optimizer sees them, parameters after `steps` steps).
+    eager=True is the default path of bench.py / train(): `loss.backward()` all-reduces the gradient buckets as they become
+    final and applies each tower's Adam on the communication stream; gradients cannot be observed before the update there."""
     from missm_benchmark_amd.engine import TrainEngine
     from missm_benchmark_amd.nn import HipCrossEntropyLoss
-    eng = TrainEngine(model, lr=lr, eager_step=False)
+    eng = TrainEngine(model, lr=lr, eager_step=eager, overlap=True)
     crit = HipCrossEntropyLoss()
-    grads = None
+    grads = {}
     for it in range(steps):
         data, missing, labels = batches
         eng.zero_grad()
         loss = crit(model({m: {k: v.cuda() for k, v in d.items()} for m, d in data.items()}, missing.cuda()), labels.cuda())
         loss.backward()
+        if eager:
+            eng.step()
+            continue
         eng.reduce_gradients()
         if it == 0:
             torch.cuda.synchronize()
@@ -71,8 +79,10 @@ def _worker(rank, world, port, q):
         dist.init_process_group("gloo", rank=rank, world_size=world)
         model = _model(seed=7 * (rank + 1)).cuda()          # different init per rank: the engine must broadcast rank 0's
         out = _train(model, _batch(rank))
+        model = _model(seed=7 * (rank + 1)).cuda()
+        _, eager_params = _train(model, _batch(rank), eager=True)
         # by value (numpy), not as shared-memory tensors: the parent may fetch the item after this process has exited
-        q.put((rank, tuple({k: v.numpy() for k, v in d.items()} for d in out), ""))
+        q.put((rank, tuple({k: v.numpy() for k, v in d.items()} for d in out + (eager_params,)), ""))
         dist.destroy_process_group()
     except Exception:  # pragma: no cover
         import traceback
@@ -108,3 +118,32 @@ def test_two_ranks_match_single_process_on_concatenated_batch():
     for k, v in sgrads.items():
         err = float((v - res[0][1][0][k]).abs().max() / v.abs().max())
         assert err < 1e-4, (k, err)
+    # the default path (eager Adam behind the bucketed, overlapped all-reduce) lands on the same parameters as the plain one
+    for r in res:
+        for k in KEYS:
+            assert torch.equal(r[1][2][k], r[1][1][k]), f"rank {r[0]}: eager/overlap path diverged from the plain path on {k}"
+    # ... and the reduced gradient is the CPU oracle's gradient of the concatenated batch (rank 0's initial parameters)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import missm_oracle as O
+    m0_ = _model(seed=7)
+    sd = {k: v.detach().clone() for k, v in m0_.state_dict().items()}
+    tiny = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=32, patch_size=16)
+    ocfg = {"image": O.VisionCfg(**tiny), "video": O.VisionCfg(add_time_attn=True, num_frames=4, **tiny)}
+    tp = {m: {k[len(f"encoder.modality_encoder.{m}."):]: v.requires_grad_(True) for k, v in sd.items()
+              if k.startswith(f"encoder.modality_encoder.{m}.")} for m in ocfg}
+    proj = {m: sd[f"encoder.modality_proj.{m}.weight"].requires_grad_(True) for m in ocfg}
+    fp = {k[len("fusion."):]: v.requires_grad_(True) for k, v in sd.items() if k.startswith("fusion.")}
+    ologits, _ = O.finetune_forward(data, torch.cat([m0, m1]), tp, ocfg, proj, {m: torch.tensor(2.6592) for m in ocfg}, fp,
+                                    ["image", "video"])
+    O.cross_entropy(ologits, torch.cat([l0, l1])).backward()
+
+    def ograd(k):
+        if k.startswith("encoder.modality_encoder."):
+            m = k.split(".")[2]
+            return tp[m][k[len(f"encoder.modality_encoder.{m}."):]].grad
+        return proj[k.split(".")[2]].grad if k.startswith("encoder.modality_proj.") else fp[k[len("fusion."):]].grad
+
+    for k in KEYS:
+        ref = ograd(k)
+        err = float((res[0][1][0][k] - ref).abs().max() / ref.abs().max())
+        assert err < 2e-3, (k, err)

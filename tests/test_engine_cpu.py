@@ -48,7 +48,14 @@ def _worker(rank, world, port, q):
             g = towers[name].flat_grad()
             g.fill_(float(rank + 1))
             towers[name]._grad_fresh = True
-            engine._tower_done(towers[name])          # what the tower's backward calls when its last kernel is enqueued
+            ranges = towers[name].bucket_ranges()
+            cover = torch.zeros(g.numel(), dtype=torch.int32)
+            for lo, hi in ranges:
+                cover[lo:hi] += 1
+            assert int(cover.min()) == 1 == int(cover.max()), "gradient buckets must tile the flat buffer exactly once"
+            for lo, hi in ranges[:-1]:
+                engine._bucket_ready(towers[name], lo, hi)   # what the tower's backward calls as each layer group finishes
+            engine._tower_done(towers[name])          # ... and when its last kernel is enqueued (reduces the tail range)
         engine.rest.grad.fill_(float(10 * (rank + 1)))
         engine.reduce_gradients()
         tot = sum(r + 1 for r in range(world))

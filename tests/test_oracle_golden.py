@@ -88,6 +88,27 @@ def test_text_tiny_causal_padding_eot():
         assert (params[k].grad - g).abs().max() < 2e-5 * max(1.0, float(g.abs().max())), k
 
 
+def test_text_full_size_causal_padding_eot():
+    """BASELINE.json configs[1]'s text tower at full size (d=768, 12 layers, head_dim 64, S=77, vocab 49408): weights by the
+    seeded recipe, outputs and gradient slices captured from stock transformers + the reference's own encoder code."""
+    fix = load_golden("text_full")
+    cfg = O.TextCfg(**fix["cfg"])
+    params = {k: v.requires_grad_(True) for k, v in O.init_tower_params(cfg, fix["seed_w"], kind="text").items()}
+    ids, mask = fix["input_ids"], fix["attention_mask"]
+    last, pooled = O.text_tower(ids, mask, params, cfg)
+    valid = mask.bool()
+    assert (last[:, :, :64] - fix["last_hidden_slice"])[valid].abs().max() < TOL
+    assert (pooled - fix["pooled"]).abs().max() < TOL
+    assert (pooled - fix["pooled_ref_encoder"]).abs().max() < TOL
+    (pooled * fix["cot_pooled"]).sum().backward()
+    for k, g in fix["grads"].items():
+        mine = params[k].grad
+        mine = mine[:64, :64] if mine.dim() == 2 else mine[:64]
+        assert (mine - g).abs().max() < 2e-5 * max(1.0, float(g.abs().max())), k
+    for k, (rows, g) in fix["grad_rows"].items():
+        assert (params[k].grad[rows][:, :64] - g).abs().max() < 2e-5 * max(1.0, float(g.abs().max())), k
+
+
 def test_text_requires_input_ids():
     import pytest
     with pytest.raises(ValueError, match="You have to specify input_ids"):

@@ -116,14 +116,17 @@ def test_full_size_vitb16_vs_reference_and_properties(pkg):
     g1 = {k: tower.get_parameter(k).grad.clone() for k in names}
     _, pooled_b = tower(x)
     assert torch.equal(pooled_b, pooled)                    # forward is deterministic
-    (pooled_b * (2.0 * cot)).sum().backward()               # gradients are overwritten per backward, and linear in the cotangent
+    tower.zero_grad(set_to_none=True)                       # (without it a second backward accumulates, like autograd)
+    (pooled_b * (2.0 * cot)).sum().backward()               # gradients are linear in the cotangent
     for k in names:
         g2 = tower.get_parameter(k).grad
         assert rel(g2, 2.0 * g1[k]) < 1e-3, k
     _, pooled_c = tower(x)
+    tower.zero_grad(set_to_none=True)
     (pooled_c * (2.0 * cot)).sum().backward()
     g3 = {k: tower.get_parameter(k).grad.clone() for k in names[:3]}   # weight gradients (GEMM + ordered split-K reduce):
     _, pooled_d = tower(x)
+    tower.zero_grad(set_to_none=True)
     (pooled_d * (2.0 * cot)).sum().backward()
     for k in names[:3]:                                     # ... bit-reproducible from run to run
         assert torch.equal(tower.get_parameter(k).grad, g3[k]), k
