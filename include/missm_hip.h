@@ -44,6 +44,15 @@ int missm_abi_version(void);
 /* Number of visible HIP devices (0 when none); never initialises a device context. */
 int missm_device_count(void);
 
+/* `ngroups` (1..8) problems of ONE shape in one call: the same linear (or its weight gradient) of several shape-identical towers -
+ * image / audio / depth / thermal (languagebind/__init__.py:75-85 encodes them one after the other).  Every operand of missm_gemm
+ * becomes an array of `ngroups` pointers (optional ones: null array, or all entries set).  Where a grouped tile kernel covers the
+ * shape (bf16; forward / dX form with a 256-row tile grid that fills the chip, weight-gradient form) the problems share ONE grid,
+ * otherwise they are launched one after the other: results do not depend on which. */
+int missm_gemm_grouped(int ngroups, const void* const* A, const void* const* B, void* const* C, int M, int N, int K, int lda, int ldb,
+                       int ldc, int trans_a, int trans_b, float alpha, const float* const* bias, const float* const* resid,
+                       const void* const* aux_in, void* const* aux_out, int ldaux, int act, int out_f32, int accumulate, int splitk,
+                       float* const* colsum_a, int dtype, void* stream);
 /* C[M,N] = alpha * A[M,K] . B[N,K]^T (+bias[N]) -> act -> (+resid) ; A, B of type `dtype`, fp32 accumulate (MFMA).
  * Output is `dtype` unless out_f32.  aux_out receives the pre-activation (for the backward), aux_in supplies it.
  * Replaces: nn.Linear inside CLIPAttention q/k/v/out_proj and CLIPMLP fc1/fc2
@@ -167,6 +176,15 @@ int missm_l2norm_scale_fwd(const float* x, float* y, int B, int D, float scale, 
 int missm_l2norm_scale_bwd(const float* dy, const float* x, float* dx, int B, int D, float scale, void* stream);
 /* loss = mean_b CE(logits[b], labels[b]) ; dlogits = (softmax - onehot) / B   (nn.CrossEntropyLoss, train_ddp.py:88,250). */
 int missm_cross_entropy(const float* logits, const long* labels, float* loss, float* dlogits, int B, int C, void* stream);
+/* KL_loss (train_ddp.py:70-79): kl_div(log_softmax(student / T), softmax(teacher / T), 'batchmean') over the rows whose row_mask byte
+ * is non-zero (all rows when row_mask is null - the reference gathers them by boolean indexing, train_ddp.py:238-240);
+ * dstudent (optional) = d loss / d student (zero on unselected rows); the teacher side is detached, as in the reference. */
+int missm_kl_loss(const float* student, const float* teacher, const unsigned char* row_mask, float* loss, float* dstudent, int B, int C,
+                  float temperature, void* stream);
+/* nn.MSELoss() of the MTD student mode (train_ddp.py:84): mean((a - b)^2); da (optional) = 2 (a - b) / n. */
+int missm_mse_loss(const float* a, const float* b, float* loss, float* da, long n, void* stream);
+/* teacher EMA of the MTD student mode (train_ddp.py:256-259): teacher = decay * teacher + (1 - decay) * student. */
+int missm_ema_update(float* teacher, const float* student, long n, float decay, void* stream);
 /* inverted dropout with a counter-based generator: y = x * mask / (1-p); mask saved as bytes (src/model/baseline.py:34). */
 int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream);
 int missm_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, void* stream);

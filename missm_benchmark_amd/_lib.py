@@ -16,6 +16,7 @@ P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_ulonglong
 SIGNATURES = {
     "missm_gemm_nt": [P, P, P, I, I, I, I, I, I, F, P, P, P, P, I, I, I, I, I, P],
     "missm_gemm": [P, P, P, I, I, I, I, I, I, I, I, F, P, P, P, P, I, I, I, I, I, P, I, P],
+    "missm_gemm_grouped": [I, P, P, P, I, I, I, I, I, I, I, I, F, P, P, P, P, I, I, I, I, I, P, I, P],
     "missm_transpose_pad": [P, P, I, I, I, I, P, I, P],
     "missm_colsum": [P, P, I, I, I, I, I, I, P],
     "missm_cast_weight": [P, P, P, I, I, I, P],
@@ -40,6 +41,9 @@ SIGNATURES = {
     "missm_l2norm_scale_fwd": [P, P, I, I, F, P],
     "missm_l2norm_scale_bwd": [P, P, P, I, I, F, P],
     "missm_cross_entropy": [P, P, P, P, I, I, P],
+    "missm_kl_loss": [P, P, P, P, P, I, I, F, P],
+    "missm_mse_loss": [P, P, P, P, L, P],
+    "missm_ema_update": [P, P, L, F, P],
     "missm_dropout_fwd": [P, P, P, L, F, U64, P],
     "missm_dropout_bwd": [P, P, P, L, F, P],
     "missm_adam_step": [P, P, P, P, L, I, F, F, F, F, F, F, P],
@@ -48,7 +52,7 @@ SIGNATURES = {
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
-ABI_VERSION = 3     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 5     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

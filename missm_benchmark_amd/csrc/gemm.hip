@@ -23,6 +23,7 @@ namespace missm {
 
 constexpr int BM = 128, BN = 128, RB = 128;  // tile rows / cols / bytes per LDS row (k-contiguous operands)
 constexpr int GEMM_THREADS = 256;
+#define MISSM_MAX_GROUPS 8
 
 struct GemmArgs {
   const void* A; const void* B; void* C;
@@ -43,7 +44,17 @@ struct GemmArgs {
   unsigned long long* dbg;  // diagnostic builds only: per-workgroup {start, loop start, loop end, end, hw id} stamps (100 MHz clock)
   int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
+  // Grouped launch (8-phase kernels only): `ngroups` problems of ONE shape - the same linear of several shape-identical towers -
+  // share a grid, so that B x 197-row towers fill the chip like one long tower does.  NT: tile rows [gi * group_tiles_m, ...)
+  // belong to group gi; TN: workgroups [gi * tiles * splitk, ...).  A group's pointers replace the ones above.
+  int ngroups, group_tiles_m;
+  struct Group { const void* A; const void* B; void* C; const float* bias; const float* resid; const void* aux_in; void* aux_out; float* colsum_a; };
+  Group grp[MISSM_MAX_GROUPS];
 };
+__device__ __forceinline__ void select_group(GemmArgs& g, const GemmArgs& all, int gi) {
+  const GemmArgs::Group& p = all.grp[gi];
+  g.A = p.A; g.B = p.B; g.C = p.C; g.bias = p.bias; g.resid = p.resid; g.aux_in = p.aux_in; g.aux_out = p.aux_out; g.colsum_a = p.colsum_a;
+}
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero16[4];   // source of zero-filled LDS chunks
 
@@ -861,9 +872,13 @@ extern "C" void missm_gemm_release_workspaces(void) {
   g_ws.clear();
 }
 
-extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
-                          int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
-                          int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream) {
+// ngroups > 1: `groups` holds the operands of `ngroups` problems of this one shape (A .. colsum_a above are group 0's).  Returns
+// MISSM_GROUPED_UNAVAILABLE (without launching anything) when no grouped kernel covers the call: the caller loops instead.
+#define MISSM_GROUPED_UNAVAILABLE 1000
+static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                     int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
+                     int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream,
+                     int ngroups, const GemmArgs::Group* groups) {
   MISSM_CHECK_ARG(M > 0 && N > 0 && K > 0, "gemm: empty problem");
   MISSM_CHECK_ARG(!colsum_a || trans_a, "gemm: colsum_a rides only in the A^T (weight-gradient) form");
   MISSM_CHECK_ARG(dtype == kBF16 || dtype == kF32, "gemm: dtype must be 0 (f32) or 1 (bf16)");
@@ -879,6 +894,11 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate; g.colsum_a = colsum_a;
+  g.ngroups = ngroups > 1 ? ngroups : 1; g.group_tiles_m = 0;
+  if (ngroups > 1) {
+    MISSM_CHECK_ARG(ngroups <= MISSM_MAX_GROUPS && groups, "gemm: too many groups");
+    for (int i = 0; i < ngroups; ++i) g.grp[i] = groups[i];
+  }
   static const int group_m_env = getenv("MISSM_GEMM_GROUP_M") ? atoi(getenv("MISSM_GEMM_GROUP_M")) : 0;
   g.group_m = 1;   // set once the tile grid is known
   g.dbg = missm_gemm_debug_buffer;
@@ -886,6 +906,14 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
   g.tiles_m = (M + BM - 1) / BM; g.tiles_n = (N + BN - 1) / BN;
   g.vec_ok = (ldc % 4 == 0) && (ldaux % 4 == 0) && ((uintptr_t)C % 16 == 0) && ((uintptr_t)resid % 16 == 0) &&
              ((uintptr_t)aux_in % 16 == 0) && ((uintptr_t)aux_out % 16 == 0);
+  for (int i = 1; i < ngroups; ++i) {
+    const GemmArgs::Group& q = groups[i];
+    g.vec_ok = g.vec_ok && ((uintptr_t)q.C % 16 == 0) && ((uintptr_t)q.resid % 16 == 0) && ((uintptr_t)q.aux_in % 16 == 0) &&
+               ((uintptr_t)q.aux_out % 16 == 0);
+    MISSM_CHECK_ARG(((uintptr_t)q.A % 16 == 0) && ((uintptr_t)q.B % 16 == 0) && ((uintptr_t)q.bias % 16 == 0), "gemm: unaligned group operand");
+    MISSM_CHECK_ARG(!q.bias == !bias && !q.resid == !resid && !q.aux_in == !aux_in && !q.aux_out == !aux_out && !q.colsum_a == !colsum_a,
+                    "gemm: the groups of one launch must use the same optional operands");
+  }
   // measured on the video tower (GROUP_M 1 / 8 / 16): QKV 668 / 732 / 756, fc1 646 / 692 / 703, fc2 (6 tile columns) 795 / 772 / 729
   g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 12 ? 16 : (g.tiles_n >= 8 ? 8 : 1));
   const int bk = dtype == kBF16 ? 64 : 32;
@@ -917,21 +945,56 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
     }
   }
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // ---- weight gradients of long activations (both operands k-major): 8-phase 256x256 kernel over K slices + ordered reduce
+  static const int use8p_tn = getenv("MISSM_GEMM_8P_TN") ? atoi(getenv("MISSM_GEMM_8P_TN")) : 1;
+  // (measured, rows = 6304: 2304x768 502 vs 455 TFLOP/s for the 128x128 split-K kernel, 3072x768 577 vs 498, 768x768 218 vs 236;
+  //  768x768 over 16384 rows 410 vs 441: the big tile needs >= 18 output tiles or a long reduction)
+  static const int tn_min_k = getenv("MISSM_GEMM_8P_TN_MINK") ? atoi(getenv("MISSM_GEMM_8P_TN_MINK")) : 4096;
+  if (use8p_tn && dtype == kBF16 && trans_a && trans_b && out_f32 && !resid && act == MISSM_ACT_NONE && !bias && M % 128 == 0 &&
+      N % 128 == 0 && K >= tn_min_k && (K >= 20000 || ((M + 255) / 256) * ((N + 255) / 256) * (ngroups > 1 ? ngroups : 1) >= 18) && (size_t)K * lda * 2 < (size_t(1) << 32) && (size_t)K * ldb * 2 < (size_t(1) << 32)) {
+    const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2;
+    int sp = 256 / (t2 * g.ngroups);
+    if (sp < 1) sp = 1;
+    int kps8 = ((K + sp - 1) / sp + 127) / 128 * 128;
+    if (kps8 < 1024) kps8 = 1024;
+    sp = (K + kps8 - 1) / kps8;
+    g.tiles_m = tm2; g.tiles_n = tn2; g.splitk = sp; g.k_per_split = kps8;
+    g.group_m = group_m_env > 0 ? group_m_env : (tn2 >= 4 ? 8 : 1);
+    if (splitk_workspace(stream, (size_t)g.ngroups * sp * t2 * (256 * 256 * sizeof(float)), &g.ws)) {
+      missm_set_error("gemm: cannot allocate the split-K workspace");
+      return MISSM_ERR_LAUNCH;
+    }
+    auto kt = use8p_tn == 2 ? gemm8p_tn_kernel<false> : gemm8p_tn_kernel<true>;
+    static bool attr_tn[2] = {false, false};
+    if (!attr_tn[use8p_tn == 2]) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kt), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+        missm_set_error("gemm: cannot raise dynamic LDS to 128 KiB");
+        return MISSM_ERR_LAUNCH;
+      }
+      attr_tn[use8p_tn == 2] = true;
+    }
+    hipLaunchKernelGGL(kt, dim3(g.ngroups * t2 * sp), dim3(512), 128 * 1024, s, g);
+    hipLaunchKernelGGL(splitk_reduce8p_kernel, dim3(g.ngroups * t2 * 8), dim3(512), 0, s, g);
+    return missm_check_launch("gemm8p_tn");
+  }
+  if (ngroups > 1 && (trans_a || trans_b)) return MISSM_GROUPED_UNAVAILABLE;
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // ---- 256x256 tile (16 waves, one workgroup per CU) for long-M NT products whose tile grid fills whole rounds of 256 CUs
   if (dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && big_env != 0 &&
       (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU)) {
-    const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2;
+    const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2 * g.ngroups;
     const int rounds = (t2 + 255) / 256;
     static const int eff_env = getenv("MISSM_GEMM_BIG_EFF") ? atoi(getenv("MISSM_GEMM_BIG_EFF")) : 75;
-    const bool fills = t2 >= 192 && t2 * 100 >= rounds * 256 * eff_env;  // >= 75 % of the last-round-padded grid is real work
+    // >= 75 % of the last-round-padded grid is real work; a grouped launch replaces `ngroups` under-filled 128x128 grids (300 small
+    // tiles on 512 slots each for N = 768), so it pays from 55 % on (N = 768: 300 big tiles = 1.17 rounds, twice as fast)
+    const bool fills = t2 >= 192 && t2 * 100 >= rounds * 256 * (g.ngroups > 1 ? 55 : eff_env);
     if (big_env == 1 || fills) {
       // A last round that would be mostly idle goes to the 128x128 kernel instead: the big tiles take the tile rows that fill
       // whole rounds of 256 CUs, the remaining rows are a second, small launch (e.g. N = 768: 591 big tiles = 2.3 rounds ->
       // 510 big tiles + 324 small ones).
       const int full = t2 / 256, rem = t2 - full * 256;
       int m_big = M;
-      if (big_env != 1 && full >= 2 && rem > 0 && rem < 160) m_big = (full * 256 / tn2) * 256;
+      if (big_env != 1 && full >= 2 && rem > 0 && rem < 160 && g.ngroups == 1) m_big = (full * 256 / tn2) * 256;
       if (m_big < M) {
         const size_t esz = 2, csz = out_f32 ? 4 : 2;
         int rc = missm_gemm(static_cast<const char*>(A) + (size_t)m_big * lda * esz, B, static_cast<char*>(C) + (size_t)m_big * ldc * csz,
@@ -942,7 +1005,8 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
         if (rc) return rc;
         g.M = m_big;
       }
-      const int tmb = (g.M + 255) / 256;
+      const int tmb = ((g.M + 255) / 256) * g.ngroups;
+      g.group_tiles_m = (g.M + 255) / 256;
       g.tiles_m = tmb; g.tiles_n = tn2;
       g.group_m = group_m_env > 0 ? group_m_env : (tn2 >= 4 ? 8 : 1);
       // 8-wave / 8-phase pipeline (gemm8p.h): whole pairs of K tiles, vector epilogue only
@@ -960,6 +1024,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
         hipLaunchKernelGGL(k8, dim3(tmb * tn2), dim3(512), 128 * 1024, s, g);
         return missm_check_launch("gemm8p");
       }
+      if (ngroups > 1) return MISSM_GROUPED_UNAVAILABLE;
       auto k = gemm_kernel<bf16, false, false, 128, 1, 4>;
       static bool attr_set = false;
       if (!attr_set) {
@@ -981,6 +1046,7 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
       return missm_check_launch("gemm256");
     }
   }
+  if (ngroups > 1) return MISSM_GROUPED_UNAVAILABLE;
   // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
@@ -1010,6 +1076,35 @@ extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, i
     else hipLaunchKernelGGL((splitk_reduce_kernel<false, 2>), dim3(tiles * 4), block, 0, s, g);
   }
   return missm_check_launch("gemm");
+}
+
+extern "C" int missm_gemm(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
+                          int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
+                          int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream) {
+  return gemm_core(A, B, C, M, N, K, lda, ldb, ldc, trans_a, trans_b, alpha, bias, resid, aux_in, aux_out, ldaux, act, out_f32, accumulate,
+                   splitk, colsum_a, dtype, stream, 1, nullptr);
+}
+
+extern "C" int missm_gemm_grouped(int ngroups, const void* const* A, const void* const* B, void* const* C, int M, int N, int K, int lda,
+                                  int ldb, int ldc, int trans_a, int trans_b, float alpha, const float* const* bias,
+                                  const float* const* resid, const void* const* aux_in, void* const* aux_out, int ldaux, int act,
+                                  int out_f32, int accumulate, int splitk, float* const* colsum_a, int dtype, void* stream) {
+  MISSM_CHECK_ARG(ngroups >= 1 && ngroups <= MISSM_MAX_GROUPS && A && B && C, "gemm_grouped: 1..8 groups");
+  GemmArgs::Group grp[MISSM_MAX_GROUPS];
+  for (int i = 0; i < ngroups; ++i)
+    grp[i] = GemmArgs::Group{A[i], B[i], C[i], bias ? bias[i] : nullptr, resid ? resid[i] : nullptr, aux_in ? aux_in[i] : nullptr,
+                             aux_out ? aux_out[i] : nullptr, colsum_a ? colsum_a[i] : nullptr};
+  if (ngroups > 1) {
+    const int rc = gemm_core(grp[0].A, grp[0].B, grp[0].C, M, N, K, lda, ldb, ldc, trans_a, trans_b, alpha, grp[0].bias, grp[0].resid,
+                             grp[0].aux_in, grp[0].aux_out, ldaux, act, out_f32, accumulate, splitk, grp[0].colsum_a, dtype, stream, ngroups, grp);
+    if (rc != MISSM_GROUPED_UNAVAILABLE) return rc;
+  }
+  for (int i = 0; i < ngroups; ++i) {      // no grouped kernel for this shape / layout / dtype: one launch per problem
+    const int rc = gemm_core(grp[i].A, grp[i].B, grp[i].C, M, N, K, lda, ldb, ldc, trans_a, trans_b, alpha, grp[i].bias, grp[i].resid,
+                             grp[i].aux_in, grp[i].aux_out, ldaux, act, out_f32, accumulate, splitk, grp[i].colsum_a, dtype, stream, 1, nullptr);
+    if (rc) return rc;
+  }
+  return MISSM_OK;
 }
 
 extern "C" int missm_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, float alpha,

@@ -45,16 +45,22 @@ __device__ __forceinline__ void stage_half(char* lds, const Gemm8pSrc& s, int wa
 
 // STAGGER: waves 4-7 run one barrier behind waves 0-3
 template <bool STAGGER>
-__global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs g) {
+__global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 8 slots x 16 KiB; slot = (4 * (K tile & 1) + h), h: B0 A0 B1 A1
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int li = lane & 15, lg = lane >> 4;
 
-  const int ntiles = g.tiles_m * g.tiles_n;
+  const int ntiles = gall.tiles_m * gall.tiles_n;
   int tm, tn;
-  tile_of(xcd_remap(blockIdx.x, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  tile_of(xcd_remap(blockIdx.x, ntiles), gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
+  GemmArgs g = gall;                         // (scalar fields only are ever read through this copy)
+  if (gall.ngroups > 1) {                    // grouped launch: this tile row's group supplies the operands
+    const int gi = tm / gall.group_tiles_m;
+    tm -= gi * gall.group_tiles_m;
+    select_group(g, gall, gi);
+  }
   const int m0 = tm * 256, n0 = tn * 256;
   const int nt = g.K >> 6;                   // K tiles (host guarantees K % 128 == 0: whole pairs)
 
@@ -108,6 +114,8 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs g) {
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
+  unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;       // diagnostic runs only (tools/gemm_timeline.py)
+  if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
 
   // ---- prologue: half tiles 0 .. 6 (K tile 0 and three quarters of K tile 1)
   stage_half<0, 0>(lds, src, wave, 0, true);
@@ -120,6 +128,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs g) {
   asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // K tile 0 has landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();                                // ... everybody's
   if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();        // waves 4-7 fall one barrier behind (re-joined after the loop)
+  if (g.dbg) t_loop = __builtin_amdgcn_s_memrealtime();
 
   bf16x8 fa[4][2], fb0[2][2], fb1[2][2];     // A half in use [i][ks]; B half 0 / 1 [j][ks]
 
@@ -207,10 +216,27 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs g) {
 #undef MISSM_8P_FENCE_ALL
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();        // waves 0-3 wait for the lagging group
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the (dropped) requests past the last K tile
+  if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
 
   // ---- epilogue: two 64 x 64 blocks per wave (A half 0 / 1), a lane owns rows 4 lg + r of each 16-row tile and the four
   // consecutive columns 64 wc + 4 li + {0, 1 (B half 0), 2, 3 (B half 1)}: the same register picture as gemm_kernel's
-  typename AuxPre<bf16>::V upre[4][4];
+  // backward-through-activation epilogue: the saved pre-activations (4 consecutive columns x 32 rows per lane) are requested
+  // for BOTH blocks at once, before any of them is used - one load per use left the wave waiting out a memory round trip
+  // thirty-two times (24 us of a 42 us tile, in-kernel stamps).  The fragment registers are free by now.
+  typename AuxPre<bf16>::V upre[2][4][4];
+  const bool have_upre = g.act == MISSM_ACT_DQGELU && !g.out_f32 && g.vec_ok && !g.accumulate && n0 + 64 * wc + 64 <= g.N;
+  if (have_upre) {
+    const bf16* U = static_cast<const bf16*>(g.aux_in) + n0 + 64 * wc + li * 4;
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = min(m0 + 128 * ha + 64 * wr + i * 16 + lg * 4 + r, g.M - 1);
+          upre[ha][i][r] = *reinterpret_cast<const bf16x4*>(U + (size_t)row * g.ldaux);
+        }
+  }
 #pragma unroll
   for (int ha = 0; ha < 2; ++ha) {
     f32x4 blk[4][4];
@@ -219,7 +245,300 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs g) {
       blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
       blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
     }
-    gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, false);
+    gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre[ha], have_upre);
+  }
+  if (g.dbg && tid == 0) {
+    const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = __builtin_amdgcn_s_memrealtime();
+    d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[5] = t_issued; d[6] = t_loop_end;
+  }
+}
+
+// =====================================================================================================================
+// The same pipeline for the weight gradient  dW[M, N] = sum_k A[k, M]^T B[k, N]  (both operands K-MAJOR: the activations dY
+// [rows, n_out] and X [rows, k_in] are read where they lie, the reduction index is the row).  A half tile is 64 k-rows x 128
+// columns (256-byte rows, 16-byte chunk c of row r stored at c ^ (tkey(r) << 1) - gemm.hip's k-major image), fragments come
+// through ds_read_b64_tr_b16 (two per fragment).  K is split over workgroups; every slice parks its 256 x 256 fp32 tile in the
+// workspace in register order and splitk_reduce8p_kernel sums the slices in slice order (bit-reproducible).  The bias
+// gradient (column sums of A) rides along: the 4 x tiles_n waves that see one A panel (wc = 0..3 of every tile column) take
+// turns by K tile - wave (tn, wc) adds up its eight A fragments on the K tiles t = 4 tn + wc (mod 4 tiles_n) - a few per cent of
+// VALU work on every wave instead of a third more on the workgroups of one tile column (measured: 169 -> 240 us that way).
+// Host guarantees: M % 128 == 0, N % 128 == 0, k_per_split % 128 == 0 (K itself may be ragged).
+// =====================================================================================================================
+template <int OFF> __device__ __forceinline__ i16x4 lds_read_tr64(unsigned addr) {
+  i16x4 v;
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "i"(OFF));
+  return v;
+}
+__device__ __forceinline__ bf16x8 join_tr(i16x4 lo, i16x4 hi) {
+  using i16x8 = __attribute__((ext_vector_type(8))) short;
+  i16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int SLOT, int H>
+__device__ __forceinline__ void stage_half_k(char* lds, const Gemm8pSrc& s, int wave, unsigned kbyte_a, unsigned kbyte_b, bool live) {
+  using lptr = __attribute__((address_space(3))) void*;
+  constexpr bool IS_A = (H == 1 || H == 3);
+  constexpr int HALF = H >> 1;
+  const __amdgpu_buffer_rsrc_t r = live ? (IS_A ? s.a[HALF] : s.b[HALF]) : s.none;
+  char* dst = lds + SLOT * 16384 + wave * 2048;
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr)dst, 16, IS_A ? s.va[0] : s.vb[0], IS_A ? kbyte_a : kbyte_b, 0, 0);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr)(dst + 1024), 16, IS_A ? s.va[1] : s.vb[1], IS_A ? kbyte_a : kbyte_b, 0, 0);
+}
+
+template <bool STAGGER>
+__global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(GemmArgs gall) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int li = lane & 15, lg = lane >> 4;
+
+  const int ntiles = gall.tiles_m * gall.tiles_n;
+  const int per_group = ntiles * gall.splitk;
+  const int gi = blockIdx.x / per_group, bid = blockIdx.x - gi * per_group;     // grouped launch: group-major workgroup ids
+  GemmArgs g = gall;
+  if (gall.ngroups > 1) select_group(g, gall, gi);
+  const int split = bid / ntiles, tix = bid - split * ntiles;
+  int tm, tn;
+  tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int kbeg = split * g.k_per_split;
+  const int kend = min(g.K, kbeg + g.k_per_split);
+  const int nt = ((kend - kbeg + 127) >> 7) << 1;   // whole pairs of K tiles; rows past K read as zeros (descriptor range)
+  if (nt <= 0) return;                        // (uniform; cannot happen with the host's slicing)
+
+  Gemm8pSrc src;
+  {
+    const bf16* A = static_cast<const bf16*>(g.A);
+    const bf16* B = static_cast<const bf16*>(g.B);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      // the range check sees voffset + soffset (measured: a 64-row window made every K tile but the first read zeros), so the
+      // descriptor spans rows 0 .. K-1 of this half's 128 columns: rows >= K (ragged end of the reduction) come back as zeros
+      const unsigned na = (m0 + 128 * h < g.M) ? (unsigned)(((size_t)(g.K - 1) * g.lda + 128) * 2) : 0u;
+      const unsigned nb = (n0 + 128 * h < g.N) ? (unsigned)(((size_t)(g.K - 1) * g.ldb + 128) * 2) : 0u;
+      src.a[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + m0 + 128 * h), 0, na, 0x00020000);
+      src.b[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B + n0 + 128 * h), 0, nb, 0x00020000);
+    }
+    src.none = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, 0, 0x00020000);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int r = 8 * wave + 4 * q + (lane >> 4);           // k row inside the half tile
+      const int c = (lane & 15) ^ (tkey(r) << 1);             // the chunk that lands at stored position lane & 15
+      src.va[q] = (unsigned)r * (unsigned)g.lda * 2u + (unsigned)c * 16u;
+      src.vb[q] = (unsigned)r * (unsigned)g.ldb * 2u + (unsigned)c * 16u;
+    }
+  }
+  const unsigned ka0 = (unsigned)kbeg * (unsigned)g.lda * 2u, kas = 64u * (unsigned)g.lda * 2u;   // byte offset of K tile 0, per-tile step
+  const unsigned kb0 = (unsigned)kbeg * (unsigned)g.ldb * 2u, kbs = 64u * (unsigned)g.ldb * 2u;
+
+  // ---- transposed fragment reads: lane (i = 4 q + p, g) addresses row 8 g + q (+ 4 for the second read), columns c0 + 4 p ..
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  unsigned aaddr[2][4], baddr[2][2];         // [K tile parity][16-column tile]
+  {
+    const int q = li >> 2, p = li & 3;
+    const int r1 = 8 * lg + q, tk = q | ((lg & 1) << 2);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int col = wr * 64 + 16 * i + 4 * p;
+      aaddr[0][i] = lds0 + (unsigned)(r1 * 256 + (((col >> 3) ^ (tk << 1)) << 4) + ((col & 7) << 1));
+      aaddr[1][i] = aaddr[0][i] + 65536u;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int col = wc * 32 + 16 * j + 4 * p;
+      baddr[0][j] = lds0 + (unsigned)(r1 * 256 + (((col >> 3) ^ (tk << 1)) << 4) + ((col & 7) << 1));
+      baddr[1][j] = baddr[0][j] + 65536u;
+    }
+  }
+
+  f32x4 acc[2][2][4][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  const bool do_cs = g.colsum_a != nullptr;                  // wave-uniform
+  const int cs_every = 4 * g.tiles_n;
+  int cs_next = 4 * tn + wc;                                 // the next K tile whose A fragments this wave sums
+  float accb[2][4];                                          // [A half][16-row tile]: column sums over this lane's k values
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[a][i] = 0.f;
+
+  stage_half_k<0, 0>(lds, src, wave, ka0, kb0, true);
+  stage_half_k<1, 1>(lds, src, wave, ka0, kb0, true);
+  stage_half_k<2, 2>(lds, src, wave, ka0, kb0, true);
+  stage_half_k<3, 3>(lds, src, wave, ka0, kb0, true);
+  stage_half_k<4, 0>(lds, src, wave, ka0 + kas, kb0 + kbs, nt > 1);
+  stage_half_k<5, 1>(lds, src, wave, ka0 + kas, kb0 + kbs, nt > 1);
+  stage_half_k<6, 2>(lds, src, wave, ka0 + kas, kb0 + kbs, nt > 1);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();
+
+  bf16x8 fa[4][2], fb0[2][2], fb1[2][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { fa[i][0] = Mma<bf16>::zero(); fa[i][1] = Mma<bf16>::zero(); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { fb0[j][0] = fb0[j][1] = fb1[j][0] = fb1[j][1] = Mma<bf16>::zero(); }
+
+#define MISSM_8P_MFMA(HA, HB, FB)                                                             \
+  __builtin_amdgcn_s_setprio(1);                                                              \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks)                                            \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i)                                             \
+      _Pragma("unroll") for (int j = 0; j < 2; ++j)                                           \
+        acc[HA][HB][i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[i][ks], FB[j][ks], acc[HA][HB][i][j], 0, 0, 0); \
+  __builtin_amdgcn_s_setprio(0);
+#define MISSM_8P_TR(ADDR, BASE) join_tr(lds_read_tr64<(BASE)>(ADDR), lds_read_tr64<(BASE) + 1024>(ADDR))
+#define MISSM_8P_READ_A(PAR, SLOT_H)                                                          \
+  _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                             \
+    fa[i][0] = MISSM_8P_TR(aaddr[PAR][i], (SLOT_H) * 16384);                                  \
+    fa[i][1] = MISSM_8P_TR(aaddr[PAR][i], (SLOT_H) * 16384 + 8192);                           \
+  }
+#define MISSM_8P_READ_B(PAR, SLOT_H, FB)                                                      \
+  _Pragma("unroll") for (int j = 0; j < 2; ++j) {                                             \
+    FB[j][0] = MISSM_8P_TR(baddr[PAR][j], (SLOT_H) * 16384);                                  \
+    FB[j][1] = MISSM_8P_TR(baddr[PAR][j], (SLOT_H) * 16384 + 8192);                           \
+  }
+#define MISSM_8P_FENCE_ALL()                                                                  \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                         \
+               : "+v"(fa[0][0]), "+v"(fa[1][0]), "+v"(fa[2][0]), "+v"(fa[3][0]), "+v"(fa[0][1]), "+v"(fa[1][1]), "+v"(fa[2][1]), \
+                 "+v"(fa[3][1]), "+v"(fb0[0][0]), "+v"(fb0[1][0]), "+v"(fb0[0][1]), "+v"(fb0[1][1]), "+v"(fb1[0][0]),            \
+                 "+v"(fb1[1][0]), "+v"(fb1[0][1]), "+v"(fb1[1][1]));                          \
+  __builtin_amdgcn_sched_barrier(0);
+#define MISSM_8P_COLSUM(HA)                                                                   \
+  if (cs_now) {                                                                               \
+    asm volatile("");      /* keeps this a real (scalar) branch */                          \
+    _Pragma("unroll") for (int i = 0; i < 4; ++i) accb[HA][i] = frag_sum(fa[i][1], frag_sum(fa[i][0], accb[HA][i]));  \
+  }
+
+  auto ktile = [&](auto par_tag, int t) {
+    constexpr int PAR = decltype(par_tag)::value;
+    constexpr int S = 4 * PAR;
+    const unsigned ka1 = ka0 + (unsigned)(t + 1) * kas, kb1 = kb0 + (unsigned)(t + 1) * kbs;
+    const unsigned ka2 = ka1 + kas, kb2 = kb1 + kbs;
+    const bool live1 = t + 1 < nt, live2 = t + 2 < nt;
+    const bool cs_now = do_cs && t == cs_next;
+    if (cs_now) cs_next += cs_every;
+    // ---- phase 0: A half 0 x B half 0 (8 + 16 transposed reads; the first nine are back at lgkmcnt(15): all of B half 0)
+    MISSM_8P_READ_B(PAR, 0, fb0)
+    MISSM_8P_READ_A(PAR, 1)
+    stage_half_k<4 * (1 - PAR) + 3, 3>(lds, src, wave, ka1, kb1, live1);
+    asm volatile("s_waitcnt lgkmcnt(15)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    MISSM_8P_FENCE_ALL()
+    MISSM_8P_MFMA(0, 0, fb0)
+    MISSM_8P_COLSUM(0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 1: A half 0 x B half 1
+    MISSM_8P_READ_B(PAR, 2, fb1)
+    stage_half_k<S + 0, 0>(lds, src, wave, ka2, kb2, live2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    MISSM_8P_FENCE_ALL()
+    MISSM_8P_MFMA(0, 1, fb1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 2: A half 1 x B half 1
+    MISSM_8P_READ_A(PAR, 3)
+    stage_half_k<S + 1, 1>(lds, src, wave, ka2, kb2, live2);
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    MISSM_8P_FENCE_ALL()
+    MISSM_8P_MFMA(1, 1, fb1)
+    MISSM_8P_COLSUM(1)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    // ---- phase 3: A half 1 x B half 0
+    stage_half_k<S + 2, 2>(lds, src, wave, ka2, kb2, live2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    MISSM_8P_MFMA(1, 0, fb0)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+  };
+  for (int t = 0; t < nt; t += 2) {
+    ktile(std::integral_constant<int, 0>{}, t);
+    ktile(std::integral_constant<int, 1>{}, t + 1);
+  }
+#undef MISSM_8P_MFMA
+#undef MISSM_8P_TR
+#undef MISSM_8P_READ_A
+#undef MISSM_8P_READ_B
+#undef MISSM_8P_FENCE_ALL
+#undef MISSM_8P_COLSUM
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (do_cs) {                                // bias gradient of rows m0 + 128 ha + 64 wr + 16 i + li (this wave's K tiles)
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v = accb[ha][i];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        const int m = m0 + 128 * ha + 64 * wr + 16 * i + li;
+        if (lg == 0 && m < g.M) atomicAdd(g.colsum_a + m, v);
+      }
+  }
+  // park the partial tile: thread t, vector v = ((ha * 2 + hb) * 4 + i) * 2 + j  ->  float4 #(v * 512 + t)   (coalesced)
+  f32x4* mine = reinterpret_cast<f32x4*>(g.ws) + ((size_t)gi * per_group + (size_t)split * ntiles + tix) * (32 * 512) + tid;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mine[(((a * 2 + b) * 4 + i) * 2 + j) * 512] = acc[a][b][i][j];
+}
+
+// sums the K slices of gemm8p_tn_kernel in slice order.  One workgroup per (tile, eighth): thread t adds up vectors
+// v = 4 e .. 4 e + 3 of every slice and stores its 16 elements: rows m0 + 128 ha + 64 wr + 16 i + 4 lg + r, column
+// n0 + 128 hb + 32 wc + 16 j + li  (16 consecutive columns per lane group: 64-byte runs)
+__global__ __launch_bounds__(512) void splitk_reduce8p_kernel(GemmArgs gall) {
+  const int ntiles = gall.tiles_m * gall.tiles_n;
+  const int gt = blockIdx.x >> 3, e = blockIdx.x & 7;
+  const int gi = gt / ntiles, tix = gt - gi * ntiles;
+  GemmArgs g = gall;
+  if (gall.ngroups > 1) select_group(g, gall, gi);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, li = lane & 15, lg = lane >> 4;
+  int tm, tn;
+  tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + ((size_t)gi * ntiles * g.splitk + tix) * (32 * 512) + (size_t)(4 * e) * 512 + tid;
+  f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  for (int sl = 0; sl < g.splitk; ++sl, p += (size_t)ntiles * (32 * 512)) {
+#pragma unroll
+    for (int v = 0; v < 4; ++v) a[v] += __builtin_nontemporal_load(p + v * 512);
+  }
+  float* C = static_cast<float*>(g.C);
+#pragma unroll
+  for (int v = 0; v < 4; ++v) {
+    const int vv = 4 * e + v, j = vv & 1, i = (vv >> 1) & 3, hb = (vv >> 3) & 1, ha = vv >> 4;
+    const int col = tn * 256 + 128 * hb + 32 * wc + 16 * j + li;
+    if (col >= g.N) continue;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = tm * 256 + 128 * ha + 64 * wr + 16 * i + 4 * lg + r;
+      if (row >= g.M) continue;
+      float* c = C + (size_t)row * g.ldc + col;
+      float x = a[v][r] * g.alpha;
+      if (g.accumulate) x += *c;
+      *c = x;
+    }
   }
 }
 

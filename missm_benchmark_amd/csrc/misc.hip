@@ -261,6 +261,62 @@ __global__ __launch_bounds__(64) void cross_entropy_kernel(const float* __restri
   if (lane == 0) *loss = part / B;
 }
 
+
+// ---- distillation losses of the student training modes (reference train_ddp.py:70-88,232-244) ---------------------------------
+// KL_loss: F.kl_div(log_softmax(s / T), softmax(t / T), reduction='batchmean') over the rows whose mask byte is non-zero (all rows
+// when mask == nullptr; the reference gathers them with boolean indexing, train_ddp.py:238-240).  One wavefront, lanes stride over
+// rows (B, C are small).  loss = sum_rows sum_c p_t (log p_t - log p_s) / n_rows ; ds = (p_s - p_t) / (T n_rows) on those rows.
+__global__ __launch_bounds__(64) void kl_loss_kernel(const float* __restrict__ s, const float* __restrict__ t, const unsigned char* __restrict__ mask,
+                                                    float* __restrict__ loss, float* __restrict__ ds, int B, int C, float inv_temp) {
+  const int lane = threadIdx.x;
+  float part = 0.f, cnt = 0.f;
+  for (int b = lane; b < B; b += 64) cnt += (!mask || mask[b]) ? 1.f : 0.f;
+  cnt = wave_sum(cnt);                       // 0 selected rows: 0 / 0 = NaN, like the reference's batchmean over an empty selection
+  for (int b = lane; b < B; b += 64) {
+    const bool on = !mask || mask[b];
+    const float* sr = s + (long)b * C;
+    const float* tr = t + (long)b * C;
+    if (on) {
+      float ms = sr[0] * inv_temp, mt = tr[0] * inv_temp;
+      for (int c = 1; c < C; ++c) { ms = fmaxf(ms, sr[c] * inv_temp); mt = fmaxf(mt, tr[c] * inv_temp); }
+      float zs = 0.f, zt = 0.f;
+      for (int c = 0; c < C; ++c) { zs += expf(sr[c] * inv_temp - ms); zt += expf(tr[c] * inv_temp - mt); }
+      const float ls = ms + logf(zs), lt = mt + logf(zt);
+      for (int c = 0; c < C; ++c) {
+        const float lps = sr[c] * inv_temp - ls, lpt = tr[c] * inv_temp - lt;
+        const float pt = expf(lpt);
+        part += pt > 0.f ? pt * (lpt - lps) : 0.f;
+        if (ds) ds[(long)b * C + c] = (expf(lps) - pt) * inv_temp / cnt;
+      }
+    } else if (ds) {
+      for (int c = 0; c < C; ++c) ds[(long)b * C + c] = 0.f;
+    }
+  }
+  part = wave_sum(part);
+  if (lane == 0) *loss = part / cnt;
+}
+
+// nn.MSELoss(): mean over all elements of (a - b)^2 ; da = 2 (a - b) / n   (b = the detached teacher features)
+__global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ loss,
+                                                      float* __restrict__ da, long n) {
+  __shared__ float red[4];
+  float part = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) {            // ONE workgroup: a fixed summation order (bit-reproducible)
+    const float d = a[i] - b[i];
+    part += d * d;
+    if (da) da[i] = 2.f * d / (float)n;
+  }
+  part = wave_sum(part);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = part;
+  __syncthreads();
+  if (threadIdx.x == 0) *loss = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
+}
+
+// teacher EMA of the MTD student mode (train_ddp.py:256-259): tea = decay * tea + (1 - decay) * stu
+__global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tea, const float* __restrict__ stu, long n, float decay) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) tea[i] = tea[i] * decay + stu[i] * (1.f - decay);
+}
+
 __device__ __forceinline__ uint32_t hash_u64(unsigned long long x) {  // splitmix64 finaliser
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -458,6 +514,25 @@ extern "C" int missm_cross_entropy(const float* logits, const long* labels, floa
   MISSM_CHECK_ARG(B > 0 && C > 0, "cross_entropy: bad shape");
   hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(64), 0, S_(stream), logits, labels, loss, dlogits, B, C);
   return missm_check_launch("cross_entropy");
+}
+
+extern "C" int missm_kl_loss(const float* student, const float* teacher, const unsigned char* row_mask, float* loss, float* dstudent, int B,
+                             int C, float temperature, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && C > 0 && temperature > 0.f, "kl_loss: bad shape");
+  hipLaunchKernelGGL(kl_loss_kernel, dim3(1), dim3(64), 0, S_(stream), student, teacher, row_mask, loss, dstudent, B, C, 1.0f / temperature);
+  return missm_check_launch("kl_loss");
+}
+
+extern "C" int missm_mse_loss(const float* a, const float* b, float* loss, float* da, long n, void* stream) {
+  MISSM_CHECK_ARG(n > 0, "mse_loss: empty input");
+  hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, S_(stream), a, b, loss, da, n);
+  return missm_check_launch("mse_loss");
+}
+
+extern "C" int missm_ema_update(float* teacher, const float* student, long n, float decay, void* stream) {
+  MISSM_CHECK_ARG(n > 0 && decay >= 0.f && decay <= 1.f, "ema_update: bad args");
+  hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), teacher, student, n, decay);
+  return missm_check_launch("ema_update");
 }
 
 extern "C" int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream) {

@@ -212,6 +212,76 @@ def fused_intra_attention(missing_index, codes: Sequence[int], xs, linears: Sequ
                                    lin2.weight, lin2.bias, *xs, *[l.weight for l in linears], *[l.bias for l in linears])
 
 
+class _InterAttentionFn(torch.autograd.Function):
+    """``modal_inter_attention`` core (reference src/model/baseline.py:221-234): a learned query token attends over the M projected
+    modality tokens through ``nn.MultiheadAttention`` with the missing modalities as ``key_padding_mask``.  Composed from the
+    library's kernels as SELF-attention over L = M + 1 positions [query | tokens]: the packed in-projection runs on all
+    positions, position 0's own key is masked out together with the missing modalities, and only position 0's output is
+    used - its gradient is the only non-zero upstream gradient, so every parameter gradient equals the reference's."""
+
+    @staticmethod
+    def forward(ctx, missing, codes, n, heads, query, in_w, in_b, out_w, out_b, *tensors):
+        xs, ws, bs = tensors[:n], tensors[n:2 * n], tensors[2 * n:]
+        B, D = xs[0].shape[0], ws[0].shape[0]
+        L = n + 1
+        dev = xs[0].device
+        X = torch.empty(B, L * D, device=dev, dtype=torch.float32)
+        X[:, :D] = query.reshape(1, D)                                  # (copy: position 0 of every sample is the query token)
+        for i in range(n):
+            ops.small_linear_fwd(xs[i].contiguous(), ws[i], bs[i], X[:, (1 + i) * D:(2 + i) * D])
+        Xf = X.view(B * L, D)
+        qkv = torch.empty(B * L, 3 * D, device=dev, dtype=torch.float32)
+        ops.small_linear_fwd(Xf, in_w, in_b, qkv)
+        km = torch.ones(B, L, device=dev, dtype=torch.int32)             # 1 = key may be attended (index bookkeeping on the codes)
+        km[:, 0] = 0
+        for i in range(n):
+            km[:, 1 + i] = (missing != codes[i]).to(torch.int32)
+        att = torch.empty(B * L, D, device=dev, dtype=torch.float32)
+        lse = torch.empty(B * heads * L, device=dev, dtype=torch.float32)
+        ops.attention_fwd(qkv, att, lse, B, L, heads, D // heads, key_mask=km)
+        c0 = att.view(B, L * D)[:, :D].contiguous()
+        y = torch.empty(B, D, device=dev, dtype=torch.float32)
+        ops.small_linear_fwd(c0, out_w, out_b, y)
+        ctx.save_for_backward(missing, query, in_w, out_w, X, qkv, att, lse, km, c0, *xs, *ws)
+        ctx.meta = (codes, n, heads, B, D, L)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        codes, n, heads, B, D, L = ctx.meta
+        missing, query, in_w, out_w, X, qkv, att, lse, km, c0 = ctx.saved_tensors[:10]
+        xs, ws = ctx.saved_tensors[10:10 + n], ctx.saved_tensors[10 + n:]
+        dev = dy.device
+        f32 = dict(device=dev, dtype=torch.float32)
+        dy = dy.contiguous()
+        dc0, dw_out, db_out = torch.empty(B, D, **f32), torch.empty_like(out_w), torch.empty(D, **f32)
+        ops.small_linear_bwd(dy, c0, out_w, dc0, dw_out, db_out)
+        datt = torch.zeros(B, L * D, **f32)
+        datt[:, :D] = dc0
+        dqkv = torch.empty_like(qkv)
+        ops.attention_bwd(qkv, att, datt.view(B * L, D), lse, dqkv, B, L, heads, D // heads, key_mask=km)
+        dX, dw_in, db_in = torch.empty(B * L, D, **f32), torch.empty_like(in_w), torch.empty(3 * D, **f32)
+        ops.small_linear_bwd(dqkv, X.view(B * L, D), in_w, dX, dw_in, db_in)
+        dXv = dX.view(B, L * D)
+        dquery = torch.zeros(D, **f32)
+        ops.colsum(dXv[:, :D], dquery, R=B)
+        out = [None, None, None, None, dquery.view_as(query), dw_in, db_in, dw_out, db_out]
+        dxs, dws, dbs = [], [], []
+        for i in range(n):
+            dx = torch.empty_like(xs[i])
+            dw, db = torch.empty_like(ws[i]), torch.empty(D, **f32)
+            ops.small_linear_bwd(dXv[:, (1 + i) * D:(2 + i) * D], xs[i].contiguous(), ws[i], dx, dw, db)
+            dxs.append(dx); dws.append(dw); dbs.append(db)
+        return tuple(out + dxs + dws + dbs)
+
+
+def fused_inter_attention(missing_index, codes: Sequence[int], xs, linears: Sequence[HipLinear], query_token, in_proj_weight, in_proj_bias,
+                          out_proj: HipLinear, num_heads: int):
+    n = len(xs)
+    return _InterAttentionFn.apply(missing_index.contiguous(), tuple(int(c) for c in codes), n, int(num_heads), query_token, in_proj_weight,
+                                   in_proj_bias, out_proj.weight, out_proj.bias, *xs, *[l.weight for l in linears], *[l.bias for l in linears])
+
+
 class _DedicatedDnnFn(torch.autograd.Function):
     """Dedicated-network fusion, reference src/model/baseline.py:333-353: z = full(cat_m x_m); the rows whose modality m is
     missing are overwritten by dedicated_m(cat of the OTHER modalities).  `sel[b]` = 0 (full network) or m + 1.  Each network
@@ -477,3 +547,59 @@ class HipCrossEntropyLoss(nn.Module):
 
     def forward(self, logits, labels):
         return _CrossEntropyFn.apply(logits, labels)
+
+
+class _KLLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, teacher, mask, temperature):
+        _gpu(student, "KL_loss")
+        student, teacher = student.contiguous(), teacher.detach().contiguous()      # g_t.detach(), train_ddp.py:77
+        loss = torch.empty((), device=student.device, dtype=torch.float32)
+        ds = torch.empty_like(student) if ctx.needs_input_grad[0] else None
+        ops.kl_loss(student, teacher, loss, ds, temperature, None if mask is None else mask.contiguous())
+        ctx.save_for_backward(ds)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return (None if ds is None else ds * g), None, None, None
+
+
+class HipKLLoss(nn.Module):
+    """the reference's ``KL_loss`` (train_ddp.py:70-79): ``kl_div(log_softmax(g_s / T), softmax(g_t.detach() / T), 'batchmean')``.
+    ``mask`` restricts it to the rows ``g_s[mask], g_t[mask]`` of the self-distillation loop (train_ddp.py:238-240) without the
+    gather."""
+
+    def __init__(self, temperature: float = 0.15):
+        super().__init__()
+        self.temperature = temperature
+
+    def forward(self, g_s, g_t, mask=None):
+        return _KLLossFn.apply(g_s, g_t, mask, self.temperature)
+
+
+class _MSELossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        _gpu(a, "MSELoss")
+        a, b = a.contiguous(), b.contiguous()
+        loss = torch.empty((), device=a.device, dtype=torch.float32)
+        da = torch.empty_like(a)
+        ops.mse_loss(a, b, loss, da)
+        ctx.save_for_backward(da)
+        ctx.need_b = b.requires_grad
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        (da,) = ctx.saved_tensors
+        d = da * g
+        return d, (-d if ctx.need_b else None)
+
+
+class HipMSELoss(nn.Module):
+    """``nn.MSELoss()`` (mean reduction) of the MTD student mode (train_ddp.py:84)"""
+
+    def forward(self, a, b):
+        return _MSELossFn.apply(a, b)

@@ -86,6 +86,55 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor, *, trans_a: bool =
     return out
 
 
+def gemm_grouped(as_, bs, outs, *, trans_a: bool = False, trans_b: bool = False, bias=None, resid=None, aux_in=None, aux_out=None,
+                 act: int = ACT_NONE, alpha: float = 1.0, accumulate: bool = False, splitk: int = 1, colsum_a=None, M=None, N=None, K=None):
+    """`len(as_)` products of ONE shape (the same linear of several shape-identical towers) in one call; every operand is a list.
+    One tower: exactly `gemm`.  The library shares one grid between the problems where a grouped kernel covers the shape."""
+    G = len(as_)
+    opt = lambda lst, i: None if lst is None else lst[i]   # noqa: E731
+    if G == 1:
+        return [gemm(as_[0], bs[0], outs[0], trans_a=trans_a, trans_b=trans_b, bias=opt(bias, 0), resid=opt(resid, 0), aux_in=opt(aux_in, 0),
+                     aux_out=opt(aux_out, 0), act=act, alpha=alpha, accumulate=accumulate, splitk=splitk, colsum_a=opt(colsum_a, 0), M=M, N=N, K=K)]
+    import ctypes as C
+    a, b, out = as_[0], bs[0], outs[0]
+    for lst, name in ((as_, "a"), (bs, "b"), (outs, "out")):
+        for t in lst:
+            _req(t, "gemm_grouped " + name)
+            if t.shape != lst[0].shape or t.stride(0) != lst[0].stride(0) or t.dtype != lst[0].dtype:
+                raise _lib.MissmError(f"gemm_grouped: the {name} operands must share shape, leading dimension and dtype")
+    for lst in (bias, resid, aux_in, aux_out, colsum_a):
+        if lst is not None and (len(lst) != G or any(t is None for t in lst) or any(t.shape != lst[0].shape or t.stride() != lst[0].stride() for t in lst)):
+            raise _lib.MissmError("gemm_grouped: optional operands are given for every group (one shape) or for none")
+    am, ak = (a.shape[1], a.shape[0]) if trans_a else (a.shape[0], a.shape[1])
+    bn, bk = (b.shape[1], b.shape[0]) if trans_b else (b.shape[0], b.shape[1])
+    M = am if M is None else M
+    N = bn if N is None else N
+    K = ak if K is None else K
+    if K > ak or K > bk or M > am or N > bn or out.shape[0] < M or out.shape[1] < N or a.dtype != b.dtype:
+        raise _lib.MissmError(f"gemm_grouped: shapes a{tuple(a.shape)} b{tuple(b.shape)} out{tuple(out.shape)} vs M{M} N{N} K{K}")
+    out_f32 = int(out.dtype == torch.float32)
+    if not out_f32 and (out.dtype != a.dtype or resid is not None or accumulate or splitk != 1):
+        raise _lib.MissmError("gemm_grouped: output must be fp32 (required for resid/accumulate/split-K) or the operand dtype")
+    aux = aux_in if aux_in is not None else aux_out
+    ldaux = aux[0].stride(0) if aux is not None else out.stride(0)
+    if aux is not None and aux[0].dtype != a.dtype:
+        raise _lib.MissmError("gemm_grouped: aux dtype must match the operands")
+    if resid is not None and (resid[0].dtype != torch.float32 or resid[0].stride(0) != out.stride(0)):
+        raise _lib.MissmError("gemm_grouped: resid must be fp32 with the output's leading dimension")
+    arr = lambda lst: None if lst is None else (C.c_void_p * G)(*[t.data_ptr() for t in lst])   # noqa: E731
+    prof = GEMM_PROFILE
+    if prof is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    _lib.call("missm_gemm_grouped", G, arr(as_), arr(bs), arr(outs), M, N, K, a.stride(0), b.stride(0), out.stride(0), int(trans_a),
+              int(trans_b), float(alpha), arr(bias), arr(resid), arr(aux_in), arr(aux_out), ldaux, act, out_f32, int(accumulate),
+              int(splitk), arr(colsum_a), dt(a), _s())
+    if prof is not None:
+        e1.record()
+        prof.append((e0, e1, 2.0 * M * N * K * G, (M, N, K, int(trans_a), int(trans_b), act, G)))
+    return outs
+
+
 def gemm_nt(a, b, out, **kw):
     """out[M,N] = a[M,K] @ b[N,K]^T ... (the forward-linear form; see gemm)."""
     return gemm(a, b, out, trans_a=False, trans_b=False, **kw)
@@ -324,6 +373,30 @@ def cross_entropy(logits, labels, loss, dlogits):
     _lib.call("missm_cross_entropy", logits.data_ptr(), labels.data_ptr(), loss.data_ptr(), _p(dlogits), logits.shape[0],
               logits.shape[1], _s())
     return loss
+
+
+def kl_loss(student, teacher, loss, dstudent, temperature, row_mask=None):
+    B, Cn = student.shape
+    if teacher.shape != student.shape or not student.is_contiguous() or not teacher.is_contiguous() or student.dtype != torch.float32:
+        raise _lib.MissmError("kl_loss: student / teacher must be contiguous fp32 [B, C] of one shape")
+    if row_mask is not None and (row_mask.dtype not in (torch.bool, torch.uint8) or row_mask.numel() != B or not row_mask.is_contiguous()):
+        raise _lib.MissmError("kl_loss: row_mask must be a contiguous bool / uint8 [B]")
+    _lib.call("missm_kl_loss", student.data_ptr(), teacher.data_ptr(), _p(row_mask), loss.data_ptr(), _p(dstudent), B, Cn,
+              float(temperature), _s())
+    return loss
+
+
+def mse_loss(a, b, loss, da):
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous() or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise _lib.MissmError("mse_loss: operands must be contiguous fp32 of one shape")
+    _lib.call("missm_mse_loss", a.data_ptr(), b.data_ptr(), loss.data_ptr(), _p(da), a.numel(), _s())
+    return loss
+
+
+def ema_update(teacher, student, decay):
+    if teacher.shape != student.shape or not teacher.is_contiguous() or not student.is_contiguous() or teacher.dtype != torch.float32:
+        raise _lib.MissmError("ema_update: operands must be contiguous fp32 of one shape")
+    _lib.call("missm_ema_update", teacher.data_ptr(), student.data_ptr(), teacher.numel(), float(decay), _s())
 
 
 def dropout_fwd(x, y, mask, p, seed):

@@ -121,6 +121,39 @@ class modal_intra_channel_attention(_FusionBase):
         return self.head(self.norm(z))
 
 
+class _MultiheadAttentionParams(nn.Module):
+    """the parameters of ``nn.MultiheadAttention(embed_dim, num_heads)`` under its state-dict keys (``in_proj_weight``,
+    ``in_proj_bias``, ``out_proj.{weight,bias}``) and its initialisation (xavier-uniform packed in-projection, zero biases)"""
+
+    def __init__(self, embed_dim: int, num_heads: int):
+        super().__init__()
+        if embed_dim % num_heads or (embed_dim // num_heads) % 8:
+            raise ValueError("fusion_dim / num_heads must be a multiple of 8")
+        self.embed_dim, self.num_heads = embed_dim, num_heads
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * embed_dim, embed_dim))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * embed_dim))
+        self.out_proj = hnn.HipLinear(embed_dim, embed_dim)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        with torch.no_grad():
+            self.out_proj.bias.zero_()
+
+
+class modal_inter_attention(_FusionBase):
+    """Inter-modality attention (reference :207-236): the projected modalities are tokens, a learned query token attends over them
+    (4 heads), a missing modality is removed from the keys; LayerNorm; Head."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim)
+        self.query_token = nn.Parameter(torch.randn(1, 1, args.fusion_dim))
+        self.attn = _MultiheadAttentionParams(args.fusion_dim, 4)
+
+    def forward(self, batch, missing_index):
+        z = hnn.fused_inter_attention(missing_index, self._codes(), [batch[m] for m in self.modality_types],
+                                      [self.modal_proj[m] for m in self.modality_types], self.query_token, self.attn.in_proj_weight,
+                                      self.attn.in_proj_bias, self.attn.out_proj, self.attn.num_heads)
+        return self.head(self.norm(z))
+
+
 class modal_dedicated_dnn(nn.Module):
     """Dedicated training (reference :333-353): one network over all modalities and one per missing-modality case over the
     remaining ones; every sample is routed to the network of its missing code."""
@@ -214,7 +247,7 @@ class modal_self_distillation(modal_distillation):
         return masks, stu, tea, self.head(self.norm(tea))
 
 
-_NOT_YET = ("inter_attention", "graph_fusion", "unified_graph")
+_NOT_YET = ("graph_fusion", "unified_graph")
 
 
 class finetune_model(nn.Module):
@@ -230,6 +263,8 @@ class finetune_model(nn.Module):
             self.fusion = modal_concat_full(args, output_dims)
         elif args.fusion_type == "intra_attention":
             self.fusion = modal_intra_channel_attention(args, output_dims)
+        elif args.fusion_type == "inter_attention":
+            self.fusion = modal_inter_attention(args, output_dims)
         elif args.fusion_type == "dedicated_dnn":
             self.fusion = modal_dedicated_dnn(args, output_dims)
         elif args.fusion_type == "regression":

@@ -10,8 +10,10 @@ checkpoint dictionaries (:298-306, :320-323) and early stopping (:311-313).  Wha
     iterable of ``(data, label, missing_index)`` batches shaped like the reference's (``data[m][k]`` tensors with the
     extra singleton dim the reference squeezes at :224-227 are accepted); ``synthetic_loader`` builds one for smoke runs;
   * checkpoints cannot be fetched by name (no network): see ``languagebind.LanguageBindModel.from_pretrained``.
-The distillation heads themselves run (Distill_tea: teacher trained with CE); the student training modes (MTD_stu / KL_stu / self_distill) need the
-MSE / KL losses and the teacher plumbing, which are queued.
+The distillation modes run too: ``Distill_tea`` (teacher trained with CE), ``MTD_stu`` (MSE to the frozen teacher's features + CE, teacher
+EMA after every step), ``KL_stu`` (KL to the teacher's features + CE) and ``self_distill`` (per-modality KL between the single-modality
+student features and the full-row teacher features on the rows where the modality is present) - reference train_ddp.py:70-88,191-199,
+232-259 - with the losses and the EMA as HIP kernels (``nn.HipKLLoss`` / ``nn.HipMSELoss`` / ``ops.ema_update``).
 """
 from __future__ import annotations
 
@@ -26,7 +28,8 @@ from torch import nn
 
 from .engine import TrainEngine
 from .languagebind import LanguageBind, to_device
-from .nn import HipCrossEntropyLoss
+from . import ops
+from .nn import HipCrossEntropyLoss, HipKLLoss, HipMSELoss
 from .src.model.baseline import finetune_model
 
 
@@ -81,9 +84,49 @@ def reduce_tensor(tensor: torch.Tensor, n: int) -> torch.Tensor:
 
 
 def get_criterion(args):
-    if args.fusion_type in ("MTD_stu", "KL_stu", "self_distill"):
-        raise NotImplementedError(f"{args.fusion_type}: distillation heads are queued (SURVEY.md 8f rank 2)")
+    """reference train_ddp.py:82-88: (distillation loss, task loss) for the student modes, the task loss alone otherwise"""
+    if args.fusion_type == "MTD_stu":
+        return HipMSELoss(), HipCrossEntropyLoss()
+    if args.fusion_type in ("KL_stu", "self_distill"):
+        return HipKLLoss(), HipCrossEntropyLoss()
     return HipCrossEntropyLoss()
+
+
+def load_teacher(args, output_dims: int, encoder_model: nn.Module, device, path: Optional[str] = None) -> nn.Module:
+    """reference train_ddp.py:191-196: the frozen teacher of the MTD / KL student modes - a second ``finetune_model`` over the SAME
+    encoder object, its weights from ``./final_model/<dataset>_Distill_tea.pth``; eval mode."""
+    tea = finetune_model(args, output_dims, encoder_model)
+    path = path or f"./final_model/{args.datasetName}_Distill_tea.pth"
+    tea.load_state_dict(torch.load(path, map_location="cpu", weights_only=False)["model_state_dict"])
+    tea.eval()
+    return tea.to(device)
+
+
+def student_loss(args, model, tea_model, distill_loss, criterion, data, labels, missing_index):
+    """the forward / loss branches of the reference's loop, train_ddp.py:231-250"""
+    if args.fusion_type in ("MTD_stu", "KL_stu"):
+        with torch.no_grad():
+            rep_t, _ = tea_model(data, torch.zeros_like(missing_index))
+        rep_s, outputs = model(data, missing_index)
+        return distill_loss(rep_s, rep_t) + criterion(outputs, labels)
+    if args.fusion_type == "self_distill":
+        missing_mask, stu_features, tea_features, outputs = model(data, missing_index)
+        dl = 0
+        for i, mask in enumerate(missing_mask):
+            dl = dl + distill_loss(stu_features[i], tea_features, mask)      # == distill_loss(s[mask], t[mask]) without the gathers
+        return 0.01 * dl / len(missing_mask) + criterion(outputs, labels)
+    outputs = model(data, missing_index)
+    outputs = outputs[1] if isinstance(outputs, tuple) else outputs              # Distill_tea: (features, logits), :246-247
+    return criterion(outputs, labels)
+
+
+def ema_teacher(tea_model: nn.Module, model: nn.Module, decay: float = 0.999):
+    """reference train_ddp.py:256-259 (MTD_stu): every teacher parameter drifts towards the student's.  Parameters the two models
+    share (the encoder is one object) are left alone: decay * p + (1 - decay) * p is p."""
+    with torch.no_grad():
+        for pt, ps in zip(tea_model.parameters(), model.parameters()):
+            if pt.data_ptr() != ps.data_ptr():
+                ops.ema_update(pt.data, ps.data.contiguous(), decay)
 
 
 def _prepare(data: Dict[str, Dict[str, torch.Tensor]], device):
@@ -169,7 +212,13 @@ def train(args, train_loader: Iterable, valid_loader: Iterable, output_dims: int
         clip_type = {m: f"LanguageBind_{m.capitalize()}" for m in args.modality_types if m != "language"}
         encoder_model = LanguageBind(clip_type=clip_type, cache_dir="./cache_dir", compute_dtype=compute_dtype, seed=args.seed)
     model = finetune_model(args, output_dims, encoder_model).to(device)
-    criterion = get_criterion(args)
+    tea_model = distill_loss = None
+    if args.fusion_type in ("MTD_stu", "KL_stu"):
+        tea_model = load_teacher(args, output_dims, encoder_model, device, getattr(args, "teacher_path", None))
+    if args.fusion_type in ("MTD_stu", "KL_stu", "self_distill"):
+        distill_loss, criterion = get_criterion(args)
+    else:
+        criterion = get_criterion(args)
     engine = TrainEngine(model, lr=args.learning_rate, weight_decay=args.weight_decay, eager_step=True)   # this loop: one backward per step
     best, best_epoch, patience, lr_bad = 0.0, 0, 0, 0
     for epoch in range(args.num_epochs):
@@ -179,11 +228,11 @@ def train(args, train_loader: Iterable, valid_loader: Iterable, output_dims: int
             engine.zero_grad()
             data = _prepare(data, device)
             labels = (label["label"] if isinstance(label, dict) else label).to(device)
-            outputs = model(data, missing_index.to(device))
-            outputs = outputs[1] if isinstance(outputs, tuple) else outputs      # Distill_tea: (features, logits), train_ddp.py:108-111,247
-            loss = criterion(outputs, labels)
+            loss = student_loss(args, model, tea_model, distill_loss, criterion, data, labels, missing_index.to(device))
             loss.backward()
             engine.step()
+            if args.fusion_type == "MTD_stu":
+                ema_teacher(tea_model, model)
             train_loss += float(loss.detach())      # the reference also syncs on loss.item() every step (:261)
             nb += 1
         val = evaluate(model, valid_loader, criterion, world_size, device)

@@ -148,11 +148,13 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
             return data
 
     model = base.finetune_model(args, classes, _Enc()).eval()
-    head_in = fusion_dim if fusion_type in ("sum", "intra_attention", "dedicated_dnn", "Distill_tea", "self_distill") else fusion_dim * len(modality_types)
+    head_in = fusion_dim if fusion_type in ("sum", "intra_attention", "inter_attention", "dedicated_dnn", "Distill_tea", "self_distill") else fusion_dim * len(modality_types)
     fp = O.init_fusion_params(modality_types, feature_dims, fusion_dim, classes, seed, head_in=head_in,
                               intra_attention=fusion_type == "intra_attention", dedicated=fusion_type == "dedicated_dnn",
-                              regression=fusion_type == "regression", distillation=fusion_type in ("Distill_tea", "self_distill"))
-    model.fusion.load_state_dict(fp, strict=False)        # (the concat head also carries statistics_<modal> buffers)
+                              regression=fusion_type == "regression", distillation=fusion_type in ("Distill_tea", "self_distill"),
+                              inter_attention=fusion_type == "inter_attention")
+    res = model.fusion.load_state_dict(fp, strict=False)
+    assert not res.unexpected_keys and all(k.startswith("statistics_") for k in res.missing_keys), res        # (the concat head also carries statistics_<modal> buffers)
     g = _gen(seed + 1)
     stats = None
     if fusion_type == "concat":                            # test.py:112-115: mean / median embeddings of the training set
@@ -193,6 +195,8 @@ def fusion_fixture(name, modality_types, batch, feature_dims, fusion_dim, classe
             lo = O.fusion_sum(e0, missing, fp, modality_types)
         elif fusion_type == "intra_attention":
             lo = O.fusion_intra_attention(e0, missing, fp, modality_types)
+        elif fusion_type == "inter_attention":
+            lo = O.fusion_inter_attention(e0, missing, fp, modality_types)
         elif fusion_type == "dedicated_dnn":
             lo = O.fusion_dedicated_dnn(e0, missing, fp, modality_types)
         elif fusion_type == "regression":
@@ -241,6 +245,55 @@ def bundle_fixture(name, seed):
     torch.save(fix, os.path.join(OUT, name + ".pt"))
     err = max(float((O.bundle_embed(pooled[m], fix["proj"][m], torch.tensor(2.6592), m) - out[m]).abs().max()) for m in out)
     print(f"{name}: ref-vs-oracle {err:.2e}")
+
+
+def losses_fixture(name, seed):
+    """The distillation losses of the student training modes, from the reference's own source: class ``KL_loss``
+    (train_ddp.py:70-79) is compiled from the file (the module itself needs tensorboard / datasets and is not importable), and
+    the self-distillation loop body (train_ddp.py:235-242) is replayed with it on seeded tensors."""
+    import ast
+    import torch.nn as nn
+    import torch.nn.functional as F
+    src = open(ref_shims.REF_ROOT + "/train_ddp.py").read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "KL_loss")
+    ns = {"torch": torch, "nn": nn, "F": F}
+    exec(compile(ast.Module(body=[cls], type_ignores=[]), "train_ddp.py", "exec"), ns)
+    kl = ns["KL_loss"]()
+    g = _gen(seed)
+    B, C = 12, 32
+    gs = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    gt = torch.randn(B, C, generator=g) * 0.3
+    l_kl = kl(gs, gt)
+    l_kl.backward()
+    fix = {"g_s": gs.detach().clone(), "g_t": gt, "temperature": kl.temperature, "kl": l_kl.detach(), "kl_grad": gs.grad.clone()}
+    a = torch.randn(B, C, generator=g, requires_grad=True)
+    b = torch.randn(B, C, generator=g)
+    l_mse = nn.MSELoss()(a, b)
+    l_mse.backward()
+    fix.update(mse_a=a.detach().clone(), mse_b=b, mse=l_mse.detach(), mse_grad=a.grad.clone())
+    # self-distillation loop body (train_ddp.py:235-242) on three "modalities"
+    masks = [torch.rand(B, generator=g) > 0.3 for _ in range(3)]
+    stu = [(torch.randn(B, C, generator=g) * 0.3).requires_grad_(True) for _ in range(3)]
+    tea = (torch.randn(B, C, generator=g) * 0.3).requires_grad_(True)
+    logits = torch.randn(B, 5, generator=g, requires_grad=True)
+    labels = torch.randint(0, 5, (B,), generator=g)
+    dl = 0
+    for i, mask in enumerate(masks):
+        t = tea[mask]
+        s_ = stu[i][mask]
+        dl += kl(s_, t)
+    loss = 0.01 * dl / len(masks) + nn.CrossEntropyLoss()(logits, labels)
+    loss.backward()
+    fix["self_distill"] = {"masks": masks, "stu": [t.detach().clone() for t in stu], "tea": tea.detach().clone(), "logits": logits.detach().clone(),
+                           "labels": labels, "loss": loss.detach(), "stu_grads": [t.grad.clone() for t in stu],
+                           "tea_grad": None if tea.grad is None else tea.grad.clone(), "logits_grad": logits.grad.clone()}
+    pt, ps = torch.randn(40, generator=g), torch.randn(40, generator=g)
+    fix["ema"] = {"tea": pt, "stu": ps, "out": pt * 0.999 + ps * (1. - 0.999)}           # train_ddp.py:259
+    torch.save(fix, os.path.join(OUT, name + ".pt"))
+    e1 = float((O.kl_loss(fix["g_s"], gt, kl.temperature) - l_kl).abs())
+    e2 = float((O.self_distill_loss(masks, fix["self_distill"]["stu"], fix["self_distill"]["tea"], fix["self_distill"]["logits"], labels) - loss).abs())
+    print(f"{name}: ref-vs-oracle KL {e1:.2e} self-distill loss {e2:.2e}")
 
 
 def missing_fixture(name):
@@ -295,6 +348,8 @@ def main():
                    fusion_type="retrieval")
     run(fusion_fixture, "fusion_intra_attention", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
         seed=23, fusion_type="intra_attention")
+    run(fusion_fixture, "fusion_inter_attention", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
+        seed=28, fusion_type="inter_attention")
     run(fusion_fixture, "fusion_dedicated_dnn", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
         seed=24, fusion_type="dedicated_dnn")
     run(fusion_fixture, "fusion_regression", ["language", "video", "audio", "image"], batch=10, feature_dims=48, fusion_dim=32, classes=5,
@@ -304,6 +359,7 @@ def main():
     run(fusion_fixture, "fusion_self_distill", ["language", "video", "image"], batch=9, feature_dims=48, fusion_dim=32, classes=4,
         seed=27, fusion_type="self_distill")
     run(bundle_fixture, "bundle", seed=12)
+    run(losses_fixture, "distill_losses", seed=31)
     run(missing_fixture, "missing_index")
     # BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224 (weights by recipe, outputs stored)
     run(vision_fixture, "vitb16_config1", "image", O.VisionCfg(), batch=4, seed_w=0, seed_x=1, store_params=False, compact=True)

@@ -328,6 +328,31 @@ def fusion_intra_attention(emb: Dict[str, Tensor], missing_index: Tensor, fp: Pa
     return head_forward(z, fp)
 
 
+def fusion_inter_attention(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                           codes: Dict[str, int] = MISSING_TYPE_INDEX, num_heads: int = 4) -> Tensor:
+    """``modal_inter_attention.forward`` src/model/baseline.py:207-236: the projected modalities are M tokens; a learned query
+    token attends over them with ``nn.MultiheadAttention(fusion_dim, 4, batch_first=True)`` (third-party torch arithmetic,
+    restated: packed in-projection, q scaled by head_dim^-1/2, missing modalities removed through ``key_padding_mask`` =
+    -inf scores, softmax over the M keys, out-projection); LayerNorm; Head."""
+    tokens = torch.stack([F.linear(emb[m], fp[f"modal_proj.{m}.weight"], fp[f"modal_proj.{m}.bias"]) for m in modality_types], dim=1)
+    pad = torch.stack([missing_index == codes[m] for m in modality_types], dim=1)               # [B, M], True = ignore
+    B, M, D = tokens.shape
+    hd = D // num_heads
+    w, b = fp["attn.in_proj_weight"], fp["attn.in_proj_bias"]
+    q = F.linear(fp["query_token"].expand(B, -1, -1), w[:D], b[:D])                              # [B, 1, D]
+    k = F.linear(tokens, w[D:2 * D], b[D:2 * D])
+    v = F.linear(tokens, w[2 * D:], b[2 * D:])
+    qh = q.view(B, 1, num_heads, hd).transpose(1, 2) * hd ** -0.5
+    kh = k.view(B, M, num_heads, hd).transpose(1, 2)
+    vh = v.view(B, M, num_heads, hd).transpose(1, 2)
+    scores = qh @ kh.transpose(-1, -2)                                                           # [B, H, 1, M]
+    scores = scores.masked_fill(pad[:, None, None, :], float("-inf"))
+    ctx = (torch.softmax(scores, dim=-1) @ vh).transpose(1, 2).reshape(B, 1, D)
+    out = F.linear(ctx, fp["attn.out_proj.weight"], fp["attn.out_proj.bias"])[:, 0, :]
+    z = F.layer_norm(out, (D,), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
 def fusion_dedicated_dnn(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
                          codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
     """``modal_dedicated_dnn.forward`` src/model/baseline.py:345-353: full network on the concatenated embeddings; rows whose
@@ -393,6 +418,31 @@ def fusion_self_distillation(emb: Dict[str, Tensor], missing_index: Tensor, fp: 
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
+
+
+def kl_loss(g_s: Tensor, g_t: Tensor, temperature: float = 0.15) -> Tensor:
+    """``KL_loss.forward`` train_ddp.py:70-79: kl_div(log_softmax(g_s / T), softmax(g_t.detach() / T), reduction='batchmean')."""
+    return F.kl_div(F.log_softmax(g_s / temperature, dim=1), F.softmax(g_t.detach() / temperature, dim=1), reduction="batchmean")
+
+
+def mse_loss(a: Tensor, b: Tensor) -> Tensor:
+    """``nn.MSELoss()`` of the MTD student mode (train_ddp.py:84)."""
+    return F.mse_loss(a, b)
+
+
+def self_distill_loss(masks: Sequence[Tensor], stu: Sequence[Tensor], tea: Tensor, logits: Tensor, labels: Tensor,
+                      temperature: float = 0.15) -> Tensor:
+    """the self-distillation branch of the training loop, train_ddp.py:235-242:
+    0.01 * mean_i KL(stu_i[mask_i], tea[mask_i]) + CE(logits, labels)."""
+    dl = 0
+    for i, mask in enumerate(masks):
+        dl = dl + kl_loss(stu[i][mask], tea[mask], temperature)
+    return 0.01 * dl / len(masks) + cross_entropy(logits, labels)
+
+
+def ema_update(tea: Tensor, stu: Tensor, decay: float = 0.999) -> Tensor:
+    """teacher EMA of the MTD student mode, train_ddp.py:256-259."""
+    return tea * decay + stu * (1.0 - decay)
 
 
 def finetune_forward(data: Dict[str, Dict[str, Tensor]], missing_index: Tensor, tower_params: Dict[str, Params],
@@ -488,7 +538,7 @@ def init_tower_params(cfg, seed: int, kind: str = "vision") -> Params:
 
 def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_dim: int, num_classes: int,
                        seed: int, head_in: Optional[int] = None, intra_attention: bool = False, dedicated: bool = False,
-                       regression: bool = False, distillation: bool = False) -> Params:
+                       regression: bool = False, distillation: bool = False, inter_attention: bool = False) -> Params:
     """Seeded init for ``modal_sum`` / ``modal_concat`` / ``modal_concat_full`` + ``Head`` (src/model/baseline.py:27-50,66-71)
     parameter names; head_in = width of the fused row (fusion_dim for sum, fusion_dim * M for the concat heads)."""
     gen = torch.Generator().manual_seed(seed)
@@ -522,6 +572,12 @@ def init_fusion_params(modality_types: Sequence[str], feature_dims: int, fusion_
                 if s != t:
                     fp[f"cross_modal_regressors.{s}_to_{t}.weight"] = _normal((fusion_dim, feature_dims), feature_dims ** -0.5, gen)
                     fp[f"cross_modal_regressors.{s}_to_{t}.bias"] = _normal((fusion_dim,), 0.02, gen)
+    if inter_attention:                          # modal_inter_attention (:218-219): query token + nn.MultiheadAttention(D, 4)
+        fp["query_token"] = _normal((1, 1, fusion_dim), 1.0, gen)
+        fp["attn.in_proj_weight"] = _normal((3 * fusion_dim, fusion_dim), fusion_dim ** -0.5, gen)
+        fp["attn.in_proj_bias"] = _normal((3 * fusion_dim,), 0.02, gen)
+        fp["attn.out_proj.weight"] = _normal((fusion_dim, fusion_dim), fusion_dim ** -0.5, gen)
+        fp["attn.out_proj.bias"] = _normal((fusion_dim,), 0.02, gen)
     if intra_attention:                          # modal_intra_channel_attention (:190-196)
         fp["fusion_representation"] = _normal((1, fusion_dim), 1.0, gen)
         fp["channel_attention.0.weight"] = _normal((fusion_dim // 4, 2 * fusion_dim), (2 * fusion_dim) ** -0.5, gen)

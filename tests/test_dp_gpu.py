@@ -119,9 +119,14 @@ def test_two_ranks_match_single_process_on_concatenated_batch():
         err = float((v - res[0][1][0][k]).abs().max() / v.abs().max())
         assert err < 1e-4, (k, err)
     # the default path (eager Adam behind the bucketed, overlapped all-reduce) lands on the same parameters as the plain one
+    # (not bit-for-bit: bias / LayerNorm gradients are summed with fp32 atomics, whose arrival order differs from run to run;
+    #  a last-bit difference in step 1 reaches every weight in step 2.  Two Adam steps of 1e-3 move a weight by ~2e-3.)
     for r in res:
         for k in KEYS:
-            assert torch.equal(r[1][2][k], r[1][1][k]), f"rank {r[0]}: eager/overlap path diverged from the plain path on {k}"
+            d = float((r[1][2][k] - r[1][1][k]).abs().max())
+            assert d < 2e-6, f"rank {r[0]}: eager/overlap path diverged from the plain path on {k}: {d:.3e}"
+    for k in KEYS:      # the two ranks of the eager run share every reduced value: bit-identical
+        assert torch.equal(res[0][1][2][k], res[1][1][2][k]), f"eager path: ranks diverged on {k}"
     # ... and the reduced gradient is the CPU oracle's gradient of the concatenated batch (rank 0's initial parameters)
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import missm_oracle as O

@@ -521,3 +521,39 @@ def test_library_loaded_before_torch_still_sees_the_gpu():
             "torch.cuda.synchronize(); print('ok', float(y.abs().mean()))\n") % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_distillation_losses_vs_reference_fixture():
+    """HipKLLoss / HipMSELoss / ema_update (student training modes, train_ddp.py:70-88,232-259) against the fixture captured from
+    the reference: values and gradients, incl. the masked form the self-distillation loop uses instead of boolean gathers."""
+    from conftest import load_golden
+    from missm_benchmark_amd import ops as OPS
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss, HipKLLoss, HipMSELoss
+    fix = load_golden("distill_losses")
+    kl = HipKLLoss(fix["temperature"])
+    gs = fix["g_s"].cuda().requires_grad_(True)
+    l = kl(gs, fix["g_t"].cuda())
+    l.backward()
+    assert abs(float(l) - float(fix["kl"])) < 1e-5 * max(1.0, abs(float(fix["kl"])))
+    assert float((gs.grad.cpu() - fix["kl_grad"]).abs().max() / fix["kl_grad"].abs().max()) < 1e-4
+    a = fix["mse_a"].cuda().requires_grad_(True)
+    l = HipMSELoss()(a, fix["mse_b"].cuda())
+    l.backward()
+    assert abs(float(l) - float(fix["mse"])) < 1e-5 and float((a.grad.cpu() - fix["mse_grad"]).abs().max()) < 1e-6
+    sd = fix["self_distill"]
+    stu = [t.cuda().requires_grad_(True) for t in sd["stu"]]
+    tea = sd["tea"].cuda().requires_grad_(True)
+    logits = sd["logits"].cuda().requires_grad_(True)
+    dl = 0
+    for i, mask in enumerate(sd["masks"]):
+        dl = dl + kl(stu[i], tea, mask.cuda())                  # == distill_loss(stu[i][mask], tea[mask])
+    loss = 0.01 * dl / len(stu) + HipCrossEntropyLoss()(logits, sd["labels"].cuda())
+    loss.backward()
+    assert abs(float(loss) - float(sd["loss"])) < 1e-5 * max(1.0, abs(float(sd["loss"])))
+    for t, g in zip(stu, sd["stu_grads"]):
+        assert float((t.grad.cpu() - g).abs().max() / g.abs().max().clamp_min(1e-12)) < 1e-4
+    assert float((logits.grad.cpu() - sd["logits_grad"]).abs().max()) < 1e-6
+    assert tea.grad is None or float(tea.grad.abs().max()) == 0.0
+    pt = fix["ema"]["tea"].cuda().clone()
+    OPS.ema_update(pt, fix["ema"]["stu"].cuda(), 0.999)
+    assert float((pt.cpu() - fix["ema"]["out"]).abs().max()) < 1e-6

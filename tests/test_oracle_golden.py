@@ -133,7 +133,7 @@ def test_fusion_sum_and_loss():
         assert (fp[k].grad - g).abs().max() < TOL, k
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression",
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_inter_attention", "fusion_dedicated_dnn", "fusion_regression",
                                   "fusion_distillation"])
 def test_fusion_concat_heads(name):
     """modal_concat (imputation statistics set through set_statistics) and modal_concat_full against the reference's outputs"""
@@ -142,6 +142,8 @@ def test_fusion_concat_heads(name):
     emb = {m: e.clone().requires_grad_(True) for m, e in fix["emb"].items()}
     if fix["fusion_type"] == "intra_attention":
         logits = O.fusion_intra_attention(emb, fix["missing_index"], fp, fix["modality_types"])
+    elif fix["fusion_type"] == "inter_attention":
+        logits = O.fusion_inter_attention(emb, fix["missing_index"], fp, fix["modality_types"])
     elif fix["fusion_type"] == "dedicated_dnn":
         logits = O.fusion_dedicated_dnn(emb, fix["missing_index"], fp, fix["modality_types"])
     elif fix["fusion_type"] == "regression":
@@ -207,3 +209,26 @@ def test_fusion_self_distillation_training_outputs():
         assert (emb[m].grad - fix["emb_grads"][m]).abs().max() < TOL
     for k, g in fix["grads"].items():
         assert (fp[k].grad - g).abs().max() < TOL, k
+
+
+def test_distillation_losses_vs_reference():
+    """KL_loss (train_ddp.py:70-79, compiled from the reference source), nn.MSELoss, the self-distillation loop body and the
+    teacher EMA against the values captured from the reference"""
+    fix = load_golden("distill_losses")
+    gs = fix["g_s"].clone().requires_grad_(True)
+    l = O.kl_loss(gs, fix["g_t"], fix["temperature"])
+    l.backward()
+    assert abs(float(l) - float(fix["kl"])) < TOL and (gs.grad - fix["kl_grad"]).abs().max() < TOL
+    a = fix["mse_a"].clone().requires_grad_(True)
+    l = O.mse_loss(a, fix["mse_b"])
+    l.backward()
+    assert abs(float(l) - float(fix["mse"])) < TOL and (a.grad - fix["mse_grad"]).abs().max() < TOL
+    sd = fix["self_distill"]
+    stu = [t.clone().requires_grad_(True) for t in sd["stu"]]
+    logits = sd["logits"].clone().requires_grad_(True)
+    l = O.self_distill_loss(sd["masks"], stu, sd["tea"], logits, sd["labels"], fix["temperature"])
+    l.backward()
+    assert abs(float(l) - float(sd["loss"])) < TOL
+    assert all((t.grad - g).abs().max() < TOL for t, g in zip(stu, sd["stu_grads"])) and (logits.grad - sd["logits_grad"]).abs().max() < TOL
+    assert sd["tea_grad"] is None or float(sd["tea_grad"].abs().max()) == 0.0       # the teacher side is detached
+    assert (O.ema_update(fix["ema"]["tea"], fix["ema"]["stu"]) - fix["ema"]["out"]).abs().max() < 1e-7

@@ -215,8 +215,8 @@ def test_fusion_sum_and_bundle_vs_reference_fixture(pkg, dtype, tol):
         assert rel(hnn.l2norm_scale(e, scale), ref) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_dedicated_dnn", "fusion_regression",
-                                  "fusion_distillation"])
+@pytest.mark.parametrize("name", ["fusion_concat", "fusion_retrieval", "fusion_intra_attention", "fusion_inter_attention",
+                                  "fusion_dedicated_dnn", "fusion_regression", "fusion_distillation"])
 def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     """fusion_type 'concat' (zero / mean / median imputation through set_statistics, test.py:112-115) and 'retrieval':
     projections written straight into their slice of the concatenated row; logits, loss and every gradient against the
@@ -228,7 +228,7 @@ def test_fusion_concat_heads_vs_reference_fixture(pkg, name):
     C = fix["logits"].shape[1]
     model = pkg.base.finetune_model(args, C, torch.nn.Identity())
     assert type(model.fusion).__name__ == {"concat": "modal_concat", "retrieval": "modal_concat_full",
-                                           "intra_attention": "modal_intra_channel_attention",
+                                           "intra_attention": "modal_intra_channel_attention", "inter_attention": "modal_inter_attention",
                                            "dedicated_dnn": "modal_dedicated_dnn", "regression": "modal_regression",
                                            "Distill_tea": "modal_distillation"}[fix["fusion_type"]]
     missing, unexpected = model.fusion.load_state_dict(fix["params"], strict=False)

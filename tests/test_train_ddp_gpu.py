@@ -115,3 +115,95 @@ def test_train_loop_checkpoints_and_learns(pkg, tmp_path, monkeypatch):
     assert set(final) == set(out.state_dict())
     for k, v in out.state_dict().items():
         assert torch.equal(v.cpu(), ck["model_state_dict"]["module." + k]), k
+    # the returned model COMPUTES with the reloaded best-checkpoint weights (not with stale compute copies of the last epoch's)
+    fresh, *_ = _tiny_model(pkg, torch.float32, seed=5)
+    fresh.load_state_dict(final)
+    fresh = fresh.cuda().eval()
+    (data, _, miss), = _batches(1, 6, 7)
+    d = {m: {k: v.squeeze(1).cuda() for k, v in x.items()} for m, x in data.items()}
+    with torch.no_grad():
+        assert torch.equal(out(d, miss.cuda()), fresh(d, miss.cuda()))
+
+
+def _oracle_embeddings(model, cfgs, tcfg, data):
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    oc = lambda c: O.VisionCfg(**{k: getattr(c, k) for k in O.VisionCfg.__dataclass_fields__})   # noqa: E731
+    tc = {"video": oc(cfgs["video"]), "image": oc(cfgs["image"]), "language": O.TextCfg(**{k: getattr(tcfg, k) for k in O.TextCfg.__dataclass_fields__})}
+    emb, leaves = {}, {}
+    for m, inputs in data.items():
+        pre = f"encoder.modality_encoder.{m}."
+        tp = {k[len(pre):]: v.requires_grad_(True) for k, v in sd.items() if k.startswith(pre)}
+        pw = sd[f"encoder.modality_proj.{m}.weight"].requires_grad_(True)
+        if m == "language":
+            _, pooled = O.text_tower(inputs["input_ids"], inputs["attention_mask"], tp, tc[m])
+        else:
+            _, pooled = O.vision_tower(inputs["pixel_values"], tp, tc[m])
+        emb[m] = O.bundle_embed(pooled, pw, torch.tensor(2.6592), m)
+        leaves[m] = (tp, pw)
+    fp = {k[len("fusion."):]: v.requires_grad_(True) for k, v in sd.items() if k.startswith("fusion.")}
+    return emb, leaves, fp
+
+
+@pytest.mark.parametrize("mode", ["KL_stu", "MTD_stu", "self_distill"])
+def test_student_training_modes_vs_oracle(pkg, mode, tmp_path, monkeypatch):
+    """The student branches of the reference's loop (train_ddp.py:191-199,232-259): frozen teacher over the SAME encoder object,
+    MSE / KL to its features (+ CE), self-distillation's per-modality masked KL, the teacher EMA - loss value and gradients of one
+    step against the CPU oracle, then the loop itself end to end."""
+    from missm_benchmark_amd import train_ddp as T
+    monkeypatch.chdir(tmp_path)
+    model0, cfgs, tcfg, margs = _tiny_model(pkg, torch.float32)
+    args = T.parse_args(["--modality_types", "language,video,image", "--feature_dims", "48", "--fusion_dim", "32", "--dropout_prob", "0.0",
+                         "--num_epochs", "2", "--learning_rate", "1e-3", "--datasetName", "synthetic", "--fusion_type", mode])
+    enc = model0.encoder
+    torch.manual_seed(3)
+    student = pkg.base.finetune_model(args, 5, enc)
+    tea_sd = None
+    if mode != "self_distill":
+        torch.manual_seed(4)
+        targs = types.SimpleNamespace(**{**vars(args), "fusion_type": "Distill_tea"})
+        teacher = pkg.base.finetune_model(targs, 5, enc)
+        os.makedirs("final_model")
+        tea_sd = {k: v.detach().cpu().clone() for k, v in teacher.state_dict().items()}
+        torch.save({"model_state_dict": tea_sd}, "final_model/synthetic_Distill_tea.pth")
+    (data, label, miss), = _batches(1, 6, 21)
+    d = {m: {k: v.squeeze(1) for k, v in x.items()} for m, x in data.items()}
+    labels = label["label"]
+    # ---- oracle
+    emb, leaves, fp = _oracle_embeddings(student, cfgs, tcfg, d)
+    mt = args.modality_types
+    if mode == "self_distill":
+        masks, stu, tea, logits = O.fusion_self_distillation(emb, miss, fp, mt)
+        oloss = O.self_distill_loss(masks, stu, tea, logits, labels)
+    else:
+        tfp = {k[len("fusion."):]: v for k, v in tea_sd.items() if k.startswith("fusion.")}
+        with torch.no_grad():
+            rep_t, _ = O.fusion_distillation({m: e.detach() for m, e in emb.items()}, torch.zeros_like(miss), tfp, mt)
+        rep_s, logits = O.fusion_distillation(emb, miss, fp, mt)
+        oloss = (O.kl_loss(rep_s, rep_t) if mode == "KL_stu" else O.mse_loss(rep_s, rep_t)) + O.cross_entropy(logits, labels)
+    oloss.backward()
+    # ---- HIP path: the loop's own helpers
+    student = student.cuda().train()
+    tea_model = T.load_teacher(args, 5, enc, "cuda:0") if mode != "self_distill" else None
+    crit = T.get_criterion(args)
+    gd = {m: {k: v.cuda() for k, v in x.items()} for m, x in d.items()}
+    loss = T.student_loss(args, student, tea_model, crit[0], crit[1], gd, labels.cuda(), miss.cuda())
+    loss.backward()
+    assert abs(float(loss.detach()) - float(oloss.detach())) < 1e-3 * max(1.0, abs(float(oloss.detach())))
+    checks = {"fusion.modal_proj.0.weight": fp["modal_proj.0.weight"].grad, "fusion.head.head.3.weight": fp["head.head.3.weight"].grad,
+              "encoder.modality_proj.video.weight": leaves["video"][1].grad,
+              "encoder.modality_encoder.image.encoder.layers.1.mlp.fc1.weight": leaves["image"][0]["encoder.layers.1.mlp.fc1.weight"].grad,
+              "encoder.modality_encoder.language.encoder.layers.0.self_attn.v_proj.weight": leaves["language"][0]["encoder.layers.0.self_attn.v_proj.weight"].grad}
+    for k, ref in checks.items():
+        assert rel(student.get_parameter(k).grad, ref) < 3e-3, (mode, k)
+    if mode == "MTD_stu":       # EMA: teacher-only parameters drift, shared (encoder) parameters are untouched
+        k = "fusion.modal_proj.0.weight"
+        before, enc_before = tea_model.get_parameter(k).detach().clone(), enc.modality_proj["video"].weight.detach().clone()
+        T.ema_teacher(tea_model, student)
+        want = O.ema_update(before.cpu(), student.get_parameter(k).detach().cpu())
+        assert float((tea_model.get_parameter(k).detach().cpu() - want).abs().max()) < 1e-7
+        assert torch.equal(enc.modality_proj["video"].weight.detach(), enc_before)
+    # ---- and the loop end to end (2 epochs on 2 batches)
+    lines = []
+    model1, *_ = _tiny_model(pkg, torch.float32)
+    T.train(args, _batches(2, 6, 100), _batches(2, 6, 100), 5, encoder_model=model1.encoder, compute_dtype=torch.float32, log=lines.append)
+    assert len(lines) == 2 and all("val loss" in s for s in lines)
