@@ -43,7 +43,46 @@ __device__ __forceinline__ void stage_half(char* lds, const Gemm8pSrc& s, int wa
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lptr)(dst + 1024), 16, IS_A ? s.va[1] : s.vb[1], kbyte, 0, 0);
 }
 
-// STAGGER: waves 4-7 run one barrier behind waves 0-3
+// tile `bid` of the launch: its group's operand pointers (grouped launch), its origin and its buffer descriptors
+__device__ __forceinline__ void gemm8p_tile(const GemmArgs& gall, int bid, GemmArgs& g, Gemm8pSrc& src, int& m0, int& n0) {
+  const int ntiles = gall.tiles_m * gall.tiles_n;
+  int tm, tn;
+  tile_of(xcd_remap(bid, ntiles), gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
+  if (gall.ngroups > 1) {                    // grouped launch: this tile row's group supplies the operands
+    const int gi = tm / gall.group_tiles_m;
+    tm -= gi * gall.group_tiles_m;
+    select_group(g, gall, gi);
+  }
+  m0 = tm * 256; n0 = tn * 256;
+  const bf16* A = static_cast<const bf16*>(g.A);
+  const bf16* B = static_cast<const bf16*>(g.B);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ra = g.M - (m0 + 128 * h), rb = g.N - (n0 + 2 * h);
+    const unsigned na = ra <= 0 ? 0u : (unsigned)min(ra, 128) * (unsigned)g.lda * 2u;
+    const unsigned nb = rb <= 0 ? 0u : (unsigned)min(rb, 254) * (unsigned)g.ldb * 2u;
+    src.a[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (size_t)(m0 + 128 * h) * g.lda), 0, na, 0x00020000);
+    src.b[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B + (size_t)(n0 + 2 * h) * g.ldb), 0, nb, 0x00020000);
+  }
+  src.none = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, 0, 0x00020000);
+}
+
+// half tiles 0 .. 6 of a tile (K tile 0 and three quarters of K tile 1)
+__device__ __forceinline__ void gemm8p_prologue(char* lds, const Gemm8pSrc& src, int wave, int nt) {
+  stage_half<0, 0>(lds, src, wave, 0, true);
+  stage_half<1, 1>(lds, src, wave, 0, true);
+  stage_half<2, 2>(lds, src, wave, 0, true);
+  stage_half<3, 3>(lds, src, wave, 0, true);
+  stage_half<4, 0>(lds, src, wave, 128, nt > 1);
+  stage_half<5, 1>(lds, src, wave, 128, nt > 1);
+  stage_half<6, 2>(lds, src, wave, 128, nt > 1);
+}
+
+// STAGGER: waves 4-7 run one barrier behind waves 0-3.
+// The grid is PERSISTENT (one workgroup per CU walks tiles bid, bid + gridDim.x, ...): once a tile's main loop has ended every
+// LDS slot is free, so the next tile's first seven half tiles are requested BEFORE this tile's epilogue - their 1.5-2.4 us of
+// latency (in-kernel stamps) and the workgroup relaunch hide under the stores.  vmcnt is in issue order: the epilogue's own
+// loads / stores are younger than those requests, so the counted wait at the top of the next tile covers them.
 template <bool STAGGER>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 8 slots x 16 KiB; slot = (4 * (K tile & 1) + h), h: B0 A0 B1 A1
@@ -51,44 +90,25 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
   const int li = lane & 15, lg = lane >> 4;
-
   const int ntiles = gall.tiles_m * gall.tiles_n;
-  int tm, tn;
-  tile_of(xcd_remap(blockIdx.x, ntiles), gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
-  GemmArgs g = gall;                         // (scalar fields only are ever read through this copy)
-  if (gall.ngroups > 1) {                    // grouped launch: this tile row's group supplies the operands
-    const int gi = tm / gall.group_tiles_m;
-    tm -= gi * gall.group_tiles_m;
-    select_group(g, gall, gi);
-  }
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nt = g.K >> 6;                   // K tiles (host guarantees K % 128 == 0: whole pairs)
+  const int nt = gall.K >> 6;                // K tiles (host guarantees K % 128 == 0: whole pairs)
 
   // ---- global -> LDS addressing.  LDS row r of a half tile holds 128 bytes of k, chunk c stored at c ^ (r & 7).
   //  A half ha : LDS row r <-> C row   m0 + 128 ha + r                       (wave wr reads rows 64 wr + 16 i + li)
   //  B half hb : LDS row r <-> C column n0 + 64 (r >> 5) + 4 (r & 15) + 2 hb + ((r >> 4) & 1)
   //              (wave wc reads rows 32 wc + 16 j + li: with both halves a lane owns 4 CONSECUTIVE columns 64 wc + 4 li + 0..3)
+  int bid = blockIdx.x;
+  GemmArgs g = gall;                         // (scalar fields only are ever read through this copy)
   Gemm8pSrc src;
-  {
-    const bf16* A = static_cast<const bf16*>(g.A);
-    const bf16* B = static_cast<const bf16*>(g.B);
+  int m0, n0;
+  gemm8p_tile(gall, bid, g, src, m0, n0);
 #pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ra = g.M - (m0 + 128 * h), rb = g.N - (n0 + 2 * h);
-      const unsigned na = ra <= 0 ? 0u : (unsigned)min(ra, 128) * (unsigned)g.lda * 2u;
-      const unsigned nb = rb <= 0 ? 0u : (unsigned)min(rb, 254) * (unsigned)g.ldb * 2u;
-      src.a[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (size_t)(m0 + 128 * h) * g.lda), 0, na, 0x00020000);
-      src.b[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B + (size_t)(n0 + 2 * h) * g.ldb), 0, nb, 0x00020000);
-    }
-    src.none = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, 0, 0x00020000);
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int r = 16 * wave + 8 * q + (lane >> 3);           // LDS row inside the half tile
-      const int c = (lane & 7) ^ (r & 7);                      // the k chunk that lands at stored position lane & 7
-      src.va[q] = (unsigned)r * (unsigned)g.lda * 2u + (unsigned)c * 16u;
-      const int col = 64 * (r >> 5) + 4 * (r & 15) + ((r >> 4) & 1);
-      src.vb[q] = (unsigned)col * (unsigned)g.ldb * 2u + (unsigned)c * 16u;
-    }
+  for (int q = 0; q < 2; ++q) {
+    const int r = 16 * wave + 8 * q + (lane >> 3);           // LDS row inside the half tile
+    const int c = (lane & 7) ^ (r & 7);                      // the k chunk that lands at stored position lane & 7
+    src.va[q] = (unsigned)r * (unsigned)gall.lda * 2u + (unsigned)c * 16u;
+    const int col = 64 * (r >> 5) + 4 * (r & 15) + ((r >> 4) & 1);
+    src.vb[q] = (unsigned)col * (unsigned)gall.ldb * 2u + (unsigned)c * 16u;
   }
 
   // ---- fragment read addresses (bytes): row * 128 + ((4 ks + lg) ^ (row & 7)) * 16; + slot and 16-row-tile immediates
@@ -102,7 +122,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
     aaddr[1][ks] = aaddr[0][ks] + 65536u;
     baddr[1][ks] = baddr[0][ks] + 65536u;
   }
+  // (measured and removed: starting the first round of workgroups (b / 8) % 8 x 2.5 us apart, so that the CUs' epilogues do
+  //  not all hit HBM in the same phase: -1..-20 % on every video shape)
+  gemm8p_prologue(lds, src, wave, nt);
 
+  for (;;) {                                 // ---- one output tile per iteration
+  unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;       // diagnostic runs only (tools/gemm_timeline.py)
+  if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
+  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
   f32x4 acc[2][2][4][2];                     // [A half][B half][16-row tile][16-column tile]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -112,20 +139,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
-  unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;       // diagnostic runs only (tools/gemm_timeline.py)
-  if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
-
-  // ---- prologue: half tiles 0 .. 6 (K tile 0 and three quarters of K tile 1)
-  stage_half<0, 0>(lds, src, wave, 0, true);
-  stage_half<1, 1>(lds, src, wave, 0, true);
-  stage_half<2, 2>(lds, src, wave, 0, true);
-  stage_half<3, 3>(lds, src, wave, 0, true);
-  stage_half<4, 0>(lds, src, wave, 128, nt > 1);
-  stage_half<5, 1>(lds, src, wave, 128, nt > 1);
-  stage_half<6, 2>(lds, src, wave, 128, nt > 1);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");            // K tile 0 has landed (this wave's pieces)
+  // K tile 0 has landed (this wave's pieces): of the requests [7 half tiles | previous epilogue | bias] at most the youngest 6
+  // are pending - on the first tile that leaves K tile 1's three half tiles in flight, later everything older than the bias
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                // ... everybody's
   if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();        // waves 4-7 fall one barrier behind (re-joined after the loop)
   if (g.dbg) t_loop = __builtin_amdgcn_s_memrealtime();
@@ -215,45 +231,57 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
 #undef MISSM_8P_READ_B
 #undef MISSM_8P_FENCE_ALL
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();        // waves 0-3 wait for the lagging group
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the (dropped) requests past the last K tile
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
+  // every fragment read of this tile is complete (phase 3 reads nothing and everybody is past its last barrier): all slots are
+  // free.  Request the NEXT tile's first half tiles now; the (dropped) requests past the last K tile are older and harmless.
+  const int nbid = bid + (int)gridDim.x;
+  const bool more = nbid < ntiles;           // wave-uniform
+  if (more) {                                // (descriptors are rebuilt after the epilogue rather than kept: scalar registers)
+    GemmArgs gn = gall;
+    Gemm8pSrc srcn = src;
+    int m0n, n0n;
+    gemm8p_tile(gall, nbid, gn, srcn, m0n, n0n);
+    gemm8p_prologue(lds, srcn, wave, nt);
+  }
 
   // ---- epilogue: two 64 x 64 blocks per wave (A half 0 / 1), a lane owns rows 4 lg + r of each 16-row tile and the four
-  // consecutive columns 64 wc + 4 li + {0, 1 (B half 0), 2, 3 (B half 1)}: the same register picture as gemm_kernel's
+  // consecutive columns 64 wc + 4 li + {0, 1 (B half 0), 2, 3 (B half 1)}: the same register picture as gemm_kernel's.
   // backward-through-activation epilogue: the saved pre-activations (4 consecutive columns x 32 rows per lane) are requested
   // for BOTH blocks at once, before any of them is used - one load per use left the wave waiting out a memory round trip
   // thirty-two times (24 us of a 42 us tile, in-kernel stamps).  The fragment registers are free by now.
-  typename AuxPre<bf16>::V upre[2][4][4];
   const bool have_upre = g.act == MISSM_ACT_DQGELU && !g.out_f32 && g.vec_ok && !g.accumulate && n0 + 64 * wc + 64 <= g.N;
-  if (have_upre) {
-    const bf16* U = static_cast<const bf16*>(g.aux_in) + n0 + 64 * wc + li * 4;
 #pragma unroll
-    for (int ha = 0; ha < 2; ++ha)
+  for (int ha = 0; ha < 2; ++ha) {
+    typename AuxPre<bf16>::V upre[4][4];     // one block's 16 rows are requested together (both blocks at once spill: 32 row addresses)
+    if (have_upre) {
+      const bf16* U = static_cast<const bf16*>(g.aux_in) + n0 + 64 * wc + li * 4;
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = min(m0 + 128 * ha + 64 * wr + i * 16 + lg * 4 + r, g.M - 1);
-          upre[ha][i][r] = *reinterpret_cast<const bf16x4*>(U + (size_t)row * g.ldaux);
+          upre[i][r] = *reinterpret_cast<const bf16x4*>(U + (size_t)row * g.ldaux);
         }
-  }
-#pragma unroll
-  for (int ha = 0; ha < 2; ++ha) {
+    }
     f32x4 blk[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
       blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
     }
-    gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre[ha], have_upre);
+    gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, have_upre);
   }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
-    d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* d = g.dbg + (size_t)bid * 8;
+    d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = t_issued;
     d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[5] = t_issued; d[6] = t_loop_end;
   }
+  if (!more) break;
+  bid = nbid;
+  g = gall;
+  gemm8p_tile(gall, bid, g, src, m0, n0);
+  }                                          // ---- next tile
 }
 
 // =====================================================================================================================

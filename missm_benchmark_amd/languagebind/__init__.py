@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import nn as hnn
-from ..towers import ClipTower, TowerConfig
+from ..towers import ClipTower, TowerConfig, run_towers
 
 LOGIT_SCALE_INIT = 2.6592  # configuration_image.py:303
 PROJECTION_DIM = 768       # train_ddp.py:31 feature_dims forces this
@@ -196,6 +196,7 @@ class LanguageBind(nn.Module):
         super().__init__()
         self.use_temp = use_temp
         self.parallel_streams = True
+        self.group_towers = _os.environ.get("MISSM_TOWER_GROUPS", "1") != "0"   # lock-step + grouped GEMMs for shape-identical towers
         self._streams = {}
         self._scale_cache = {}
         encoders, projs = {}, {}
@@ -226,8 +227,7 @@ class LanguageBind(nn.Module):
             t.set_compute_dtype(dtype)
         return self
 
-    def _embed(self, key, value):
-        pooled = self.modality_encoder[key](**value)[1]
+    def _finish(self, key, pooled):
         emb = self.modality_proj[key](pooled)
         scale = 1.0
         if self.use_temp and key != "language":
@@ -240,41 +240,71 @@ class LanguageBind(nn.Module):
             scale = cached[2]
         return hnn.l2norm_scale(emb, scale)
 
+    def _embed(self, key, value):
+        return self._finish(key, self.modality_encoder[key](**value)[1])
+
+    def _embed_unit(self, keys, values):
+        """one work unit: a single tower, or several shape-identical ones in lock-step (towers.run_towers)"""
+        if len(keys) == 1:
+            return {keys[0]: self._embed(keys[0], values[0])}
+        outs = run_towers([self.modality_encoder[k] for k in keys], values)
+        return {k: self._finish(k, o[1]) for k, o in zip(keys, outs)}
+
+    def _units(self, inputs):
+        """[(keys, values)]: modalities whose towers share config, compute dtype and input shape form one unit (their linears are
+        launched as grouped GEMMs: four B x 197-row towers fill the chip like one long tower); most expensive unit first"""
+        cost = lambda kv: -sum(v.numel() for v in kv[1].values() if torch.is_tensor(v))   # noqa: E731
+        order = sorted(inputs.items(), key=cost)
+        units, by_sig = [], {}
+        for key, value in order:
+            t = self.modality_encoder[key]
+            px = value.get("pixel_values") if isinstance(value, dict) else None
+            sig = None
+            if self.group_towers and key != "language" and torch.is_tensor(px) and isinstance(t, ClipTower):
+                sig = (repr(t.config), t.compute_dtype, tuple(px.shape))
+            if sig is not None and sig in by_sig:
+                by_sig[sig][0].append(key); by_sig[sig][1].append(value)
+                continue
+            unit = ([key], [value])
+            units.append(unit)
+            if sig is not None:
+                by_sig[sig] = unit
+        return units
+
     def forward(self, inputs):
         """Same contract as the reference loop (languagebind/__init__.py:75-85).  The reference encodes the modalities one
-        after the other on one stream; here the towers are spread over two HIP streams, so the under-filled launches of the
-        B x 197-token towers (150-600 workgroups on 256 CUs) overlap the video tower's.
-        autograd replays each tower's backward on the stream its forward ran on."""
+        after the other on one stream; here shape-identical towers run in lock-step as one unit, and the units are spread over
+        two HIP streams.  autograd replays each unit's backward on the stream its forward ran on."""
         dev = next(iter(self.modality_proj.values())).weight.device
-        if dev.type != "cuda" or not self.parallel_streams or len(inputs) < 2:
-            return {key: self._embed(key, value) for key, value in inputs.items()}
-        main = torch.cuda.current_stream()
-        # Enqueue the most expensive tower first (video: T x the tokens of an image-like tower).  Its forward then overlaps the
-        # under-filled launches of the small towers from the start, and - autograd replays later-created nodes first - its
-        # backward runs last, alone, with full grids, instead of the step ending and the next one starting on the small
-        # towers only (measured: 358 -> 368 samples/s at B = 32, 5 modalities).  Results do not depend on the order.
-        cost = lambda kv: -sum(v.numel() for v in kv[1].values() if torch.is_tensor(v))   # noqa: E731
+        units = self._units(inputs)
         done = {}
-        order = sorted(inputs.items(), key=cost)
-        # two streams: the most expensive tower on its own, all the others one after the other on a second one (measured at
+        if dev.type != "cuda" or not self.parallel_streams or len(units) < 2:
+            for keys, values in units:
+                done.update(self._embed_unit(keys, values))
+            return {key: done[key] for key in inputs}
+        main = torch.cuda.current_stream()
+        # Enqueue the most expensive unit first (video: T x the tokens of an image-like tower).  Its forward then overlaps the
+        # launches of the others from the start, and - autograd replays later-created nodes first - its backward runs last,
+        # alone, with full grids (measured: 358 -> 368 samples/s at B = 32, 5 modalities).  Results do not depend on the order.
+        # Two streams: the most expensive unit on its own, all the others one after the other on a second one (measured at
         # B = 32, video + 4 image-like towers: one stream per tower 371, two shared streams for the four 372, one 379 samples/s;
         # raising the video stream's priority 364)
-        default_group = {key: ("_big" if i == 0 else "_rest") for i, (key, _) in enumerate(order)}
-        for key, value in order:
-            skey = _STREAM_GROUP.get(key, default_group[key] if not _STREAM_GROUP else key)
+        used = []
+        for i, (keys, values) in enumerate(units):
+            skey = _STREAM_GROUP.get(keys[0], ("_big" if i == 0 else "_rest") if not _STREAM_GROUP else keys[0])
             st = self._streams.get(skey)
             if st is None:
-                st = self._streams[skey] = torch.cuda.Stream(device=dev, priority=_STREAM_PRIO.get(key, 0))
-            self._streams[key] = st
+                st = self._streams[skey] = torch.cuda.Stream(device=dev, priority=_STREAM_PRIO.get(keys[0], 0))
+            used.append(st)
             st.wait_stream(main)
             with torch.cuda.stream(st):
-                out = self._embed(key, value)
-            out.record_stream(main)
-            done[key] = out
-        outputs = {key: done[key] for key in inputs}      # the reference's (input) order
-        for key in inputs:
-            main.wait_stream(self._streams[key])
-        return outputs
+                outs = self._embed_unit(keys, values)
+            for out in outs.values():
+                out.record_stream(main)
+            done.update(outs)
+        for st in used:
+            main.wait_stream(st)
+        return {key: done[key] for key in inputs}      # the reference's (input) order
 
 
 def to_device(x, device):

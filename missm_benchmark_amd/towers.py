@@ -351,17 +351,86 @@ class ClipTower(nn.Module):
         last, pooled = _TowerFn.apply(self._anchor, self, inputs, need_grad, *params)
         return (last, pooled)
 
-    # ------------------------------------------------------------------ forward implementation
+    # ------------------------------------------------------------------ forward / backward implementation
     def _forward_impl(self, inputs, save: bool):
-        c, st, T = self.config, self._store, self.compute_dtype
-        dev = st.master.device
-        d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
-        hd = d // H
-        S = c.seq_len
-        s = SimpleNamespace(layers=[], save=save)
-        f32 = dict(device=dev, dtype=torch.float32)
-        if c.kind == "vision":
-            px = inputs[0]
+        return forward_lanes([self], [inputs], save)[0]
+
+    def _backward_impl(self, s, d_last, d_pooled):
+        backward_lanes([self], [s], [d_last], [d_pooled])
+
+    def _begin_backward(self):
+        """torch.autograd semantics for .grad: a backward ADDS to gradients that have not been consumed yet - a second
+        micro-batch, the reference's teacher and student sharing one encoder, a tower called twice in a step.  "Consumed"
+        = the engine's optimizer step ran (_grad_fresh cleared) or zero_grad(set_to_none=True) detached the views; after
+        zero_grad(set_to_none=False) the buffers hold zeros, and adding to them is the same as storing.  In "autograd"
+        gradient mode the values are handed to autograd, which does its own accumulation."""
+        st = self._store
+        self._accumulate = bool(self._grad_fresh and _GRAD_MODE == "direct" and self._plist[0].grad is not None
+                                and st.grad is not None and self._plist[0].grad.data_ptr() == st.gview(self._param_names[0]).data_ptr())
+        if not self._accumulate:
+            st.zero_accumulated()
+
+    def attach_grads(self):
+        """p.grad of every parameter = its view into the flat gradient buffer.  Runs after every backward on the host thread
+        that feeds the GPU, so the (parameter, view) pairs are resolved once: walking ~200 dotted names per call cost 0.7 ms,
+        during which the stream of the following tower's backward sat empty."""
+        st = self._store
+        grad = st.ensure_grad()
+        cache = self._grad_cache
+        if cache is None or cache[0] is not grad:
+            cache = self._grad_cache = (grad, [(self.get_parameter(n), st.gview(n)) for n in self._param_names])
+        for p, gv in cache[1]:
+            if p.grad is not gv:
+                p.grad = gv
+
+
+
+# ======================================================================================================================
+# Lock-step execution of `lanes` = one or several shape-identical towers (same config, compute dtype and input geometry).
+# Every op that is not a GEMM is launched once per lane; every linear, its input gradient and its weight gradient are ONE
+# grouped call (ops.gemm_grouped): the library then shares one tile grid between the lanes, so that four B x 197-row towers
+# fill the chip like one long tower (their own 128x128 grids fill 59-88 % of it and run at ~480 TFLOP/s against ~1000 for the
+# video tower's).  With one lane this is exactly the single-tower path.
+# ======================================================================================================================
+def _linear_bwd_lanes(lanes, dys, xs, wts, g_ws, g_bs, rows, dx_outs=None, act=ops.ACT_NONE, aux_ins=None):
+    """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result STORED
+    into the fp32 gradient - or ADDED to it when this backward accumulates, ClipTower._begin_backward); db += colsum(dy) riding
+    in the same GEMM (tail of the gradient buffer); dx = dy W through the transposed compute-dtype shadow (NT form)."""
+    ops.gemm_grouped(dys, xs, g_ws, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_bs, accumulate=lanes[0]._accumulate)
+    if dx_outs is not None:
+        ops.gemm_grouped(dys, wts, dx_outs, act=act, aux_in=aux_ins, M=rows)
+    return dx_outs
+
+
+def lanes_compatible(towers, inputs) -> bool:
+    t0 = towers[0]
+    if len(towers) == 1:
+        return True
+    if any(t.config != t0.config or t.compute_dtype != t0.compute_dtype for t in towers):
+        return False
+    if t0.config.kind != "vision":
+        return False
+    shapes = {tuple(i[0].shape) for i in inputs}
+    return len(shapes) == 1 and all(i[0].device == inputs[0][0].device for i in inputs)
+
+
+def forward_lanes(towers, inputs, save: bool):
+    """returns [(state, last_hidden_state, pooled_output)] per lane"""
+    t0 = towers[0]
+    c, T = t0.config, t0.compute_dtype
+    G = range(len(towers))
+    sts = [t._store for t in towers]
+    dev = sts[0].master.device
+    d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
+    hd = d // H
+    S = c.seq_len
+    ss = [SimpleNamespace(layers=[], save=save) for _ in G]
+    f32 = dict(device=dev, dtype=torch.float32)
+    E = lambda *shape, **kw: [torch.empty(*shape, **kw) for _ in G]      # noqa: E731  one buffer per lane
+    if c.kind == "vision":
+        pxs = []
+        for g in G:
+            px = inputs[g][0]
             if px.dim() == 7:
                 b_new, pair_new, Tf, bs_new, ch, hh, ww = px.shape
                 B = b_new * pair_new * bs_new
@@ -379,217 +448,229 @@ class ClipTower(nn.Module):
                 raise ValueError(f"pixel_values spatial/channel shape {tuple(px.shape)} does not match the tower config")
             if c.add_time_attn and Tf != c.num_frames:
                 raise ValueError(f"time attention is configured for {c.num_frames} frames, got {Tf}")
-            N = B * Tf
-            P = S - 1
-            Kp = c.num_channels * c.patch_size ** 2
-            U = torch.empty(N * P, Kp, device=dev, dtype=T)
-            ops.unfold_patches(px, U, c.patch_size)
-            pe = torch.empty(N * P, d, device=dev, dtype=T)
-            ops.gemm_nt(U, self._w("patch")[0], pe)
-            x0 = torch.empty(N * S, d, **f32)
-            ops.embed_assemble(pe, st.view("embeddings.class_embedding"), st.view("embeddings.position_embedding.weight"), x0, N, S, d)
-            h = torch.empty(N * S, d, **f32)
-            m0, r0 = torch.empty(N * S, **f32), torch.empty(N * S, **f32)
-            ops.layernorm_fwd(x0, st.view("pre_layrnorm.weight"), st.view("pre_layrnorm.bias"), h, m0, r0, N * S, d, c.layer_norm_eps)
-            s.emb = (U, x0, m0, r0) if save else None
-            causal, key_mask = False, None
-        else:
-            ids, amask = inputs
-            ids = ids.to(dev).view(-1, ids.shape[-1]).contiguous().long()
-            B, Sx = ids.shape
-            if Sx > c.max_position_embeddings:
-                raise ValueError("sequence longer than max_position_embeddings")
-            S, Tf, N = Sx, 1, B
-            h = torch.empty(N * S, d, **f32)
-            ops.token_embed_fwd(ids, st.view("embeddings.token_embedding.weight"), st.view("embeddings.position_embedding.weight"), h, B, S, d)
-            causal = True
-            key_mask = amask.to(dev).view(B, S).to(torch.int32).contiguous() if amask is not None else None
-            s.ids = ids
-        rows = N * S
-        s.geom = (B, Tf, N, S, rows)
-        act = ops.ACT_CODE[c.hidden_act]
-        for i in range(c.num_hidden_layers):
-            L = self._lp[i]
-            pfx = f"encoder.layers.{i}"
-            rec = SimpleNamespace()
-            if c.add_time_attn:
-                xt = torch.empty(rows, d, device=dev, dtype=T)
-                mt, rt = torch.empty(rows, **f32), torch.empty(rows, **f32)
-                ops.layernorm_fwd(h, L.tln_w, L.tln_b, xt, mt, rt, rows, d, c.layer_norm_eps,
-                                  add=L.temb if Tf != 1 else None, add_div=S, add_mod=Tf)
-                qkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
-                ops.gemm_nt(xt, self._w(f"{pfx}.tqkv")[0], qkv, bias=L.tqkv_b)
-                ctx = torch.empty(rows, d, device=dev, dtype=T)
-                lse = torch.empty(B * S * H * Tf, **f32)
-                ops.attention_fwd(qkv, ctx, lse, B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
-                h2 = torch.empty(rows, d, **f32)
-                ops.gemm_nt(ctx, self._w(f"{pfx}.tout")[0], h2, bias=L.tout_b, resid=h)
-                if save:
-                    rec.t = (h, xt, mt, rt, qkv, ctx, lse)
-                h = h2
-            x1 = torch.empty(rows, d, device=dev, dtype=T)
-            m1, r1 = torch.empty(rows, **f32), torch.empty(rows, **f32)
-            ops.layernorm_fwd(h, L.ln1_w, L.ln1_b, x1, m1, r1, rows, d, c.layer_norm_eps)
-            qkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
-            ops.gemm_nt(x1, self._w(f"{pfx}.qkv")[0], qkv, bias=L.qkv_b)
-            ctx = torch.empty(rows, d, device=dev, dtype=T)
-            lse = torch.empty(N * H * S, **f32)
-            ops.attention_fwd(qkv, ctx, lse, N, S, H, hd, causal=causal, key_mask=key_mask)
-            h2 = torch.empty(rows, d, **f32)
-            ops.gemm_nt(ctx, self._w(f"{pfx}.out")[0], h2, bias=L.out_b, resid=h)
-            x2 = torch.empty(rows, d, device=dev, dtype=T)
-            m2, r2 = torch.empty(rows, **f32), torch.empty(rows, **f32)
-            ops.layernorm_fwd(h2, L.ln2_w, L.ln2_b, x2, m2, r2, rows, d, c.layer_norm_eps)
-            a = torch.empty(rows, f, device=dev, dtype=T)
-            u = torch.empty(rows, f, device=dev, dtype=T) if save else None
-            ops.gemm_nt(x2, self._w(f"{pfx}.fc1")[0], a, bias=L.fc1_b, act=act, aux_out=u)
-            h3 = torch.empty(rows, d, **f32)
-            ops.gemm_nt(a, self._w(f"{pfx}.fc2")[0], h3, bias=L.fc2_b, resid=h2)
+            pxs.append(px)
+        N = B * Tf
+        P = S - 1
+        Kp = c.num_channels * c.patch_size ** 2
+        U = E(N * P, Kp, device=dev, dtype=T)
+        for g in G:
+            ops.unfold_patches(pxs[g], U[g], c.patch_size)
+        pe = E(N * P, d, device=dev, dtype=T)
+        ops.gemm_grouped(U, [t._w("patch")[0] for t in towers], pe)
+        x0, h = E(N * S, d, **f32), E(N * S, d, **f32)
+        m0, r0 = E(N * S, **f32), E(N * S, **f32)
+        for g in G:
+            st = sts[g]
+            ops.embed_assemble(pe[g], st.view("embeddings.class_embedding"), st.view("embeddings.position_embedding.weight"), x0[g], N, S, d)
+            ops.layernorm_fwd(x0[g], st.view("pre_layrnorm.weight"), st.view("pre_layrnorm.bias"), h[g], m0[g], r0[g], N * S, d, c.layer_norm_eps)
+            ss[g].emb = (U[g], x0[g], m0[g], r0[g]) if save else None
+        causal, key_mask = False, [None for _ in G]
+    else:
+        (ids, amask), = inputs          # (text towers are never grouped)
+        ids = ids.to(dev).view(-1, ids.shape[-1]).contiguous().long()
+        B, Sx = ids.shape
+        if Sx > c.max_position_embeddings:
+            raise ValueError("sequence longer than max_position_embeddings")
+        S, Tf, N = Sx, 1, B
+        h = E(N * S, d, **f32)
+        ops.token_embed_fwd(ids, sts[0].view("embeddings.token_embedding.weight"), sts[0].view("embeddings.position_embedding.weight"), h[0], B, S, d)
+        causal = True
+        key_mask = [amask.to(dev).view(B, S).to(torch.int32).contiguous() if amask is not None else None]
+        ss[0].ids = ids
+    rows = N * S
+    for g in G:
+        ss[g].geom = (B, Tf, N, S, rows)
+    act = ops.ACT_CODE[c.hidden_act]
+    W = lambda key, which: [t._w(key)[which] for t in towers]            # noqa: E731
+    for i in range(c.num_hidden_layers):
+        L = [t._lp[i] for t in towers]
+        pfx = f"encoder.layers.{i}"
+        recs = [SimpleNamespace() for _ in G]
+        if c.add_time_attn:
+            xt = E(rows, d, device=dev, dtype=T)
+            mt, rt = E(rows, **f32), E(rows, **f32)
+            for g in G:
+                ops.layernorm_fwd(h[g], L[g].tln_w, L[g].tln_b, xt[g], mt[g], rt[g], rows, d, c.layer_norm_eps,
+                                  add=L[g].temb if Tf != 1 else None, add_div=S, add_mod=Tf)
+            qkv = E(rows, 3 * d, device=dev, dtype=T)
+            ops.gemm_grouped(xt, W(f"{pfx}.tqkv", 0), qkv, bias=[l.tqkv_b for l in L])
+            ctx = E(rows, d, device=dev, dtype=T)
+            lse = E(B * S * H * Tf, **f32)
+            for g in G:
+                ops.attention_fwd(qkv[g], ctx[g], lse[g], B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
+            h2 = E(rows, d, **f32)
+            ops.gemm_grouped(ctx, W(f"{pfx}.tout", 0), h2, bias=[l.tout_b for l in L], resid=h)
             if save:
-                rec.a = (h, x1, m1, r1, qkv, ctx, lse)
-                rec.m = (h2, x2, m2, r2, u, a)
-                s.layers.append(rec)
-            h = h3
-        s.key_mask, s.causal = key_mask, causal
+                for g in G:
+                    recs[g].t = (h[g], xt[g], mt[g], rt[g], qkv[g], ctx[g], lse[g])
+            h = h2
+        x1 = E(rows, d, device=dev, dtype=T)
+        m1, r1 = E(rows, **f32), E(rows, **f32)
+        for g in G:
+            ops.layernorm_fwd(h[g], L[g].ln1_w, L[g].ln1_b, x1[g], m1[g], r1[g], rows, d, c.layer_norm_eps)
+        qkv = E(rows, 3 * d, device=dev, dtype=T)
+        ops.gemm_grouped(x1, W(f"{pfx}.qkv", 0), qkv, bias=[l.qkv_b for l in L])
+        ctx = E(rows, d, device=dev, dtype=T)
+        lse = E(N * H * S, **f32)
+        for g in G:
+            ops.attention_fwd(qkv[g], ctx[g], lse[g], N, S, H, hd, causal=causal, key_mask=key_mask[g])
+        h2 = E(rows, d, **f32)
+        ops.gemm_grouped(ctx, W(f"{pfx}.out", 0), h2, bias=[l.out_b for l in L], resid=h)
+        x2 = E(rows, d, device=dev, dtype=T)
+        m2, r2 = E(rows, **f32), E(rows, **f32)
+        for g in G:
+            ops.layernorm_fwd(h2[g], L[g].ln2_w, L[g].ln2_b, x2[g], m2[g], r2[g], rows, d, c.layer_norm_eps)
+        a = E(rows, f, device=dev, dtype=T)
+        u = E(rows, f, device=dev, dtype=T) if save else None
+        ops.gemm_grouped(x2, W(f"{pfx}.fc1", 0), a, bias=[l.fc1_b for l in L], act=act, aux_out=u)
+        h3 = E(rows, d, **f32)
+        ops.gemm_grouped(a, W(f"{pfx}.fc2", 0), h3, bias=[l.fc2_b for l in L], resid=h2)
+        if save:
+            for g in G:
+                recs[g].a = (h[g], x1[g], m1[g], r1[g], qkv[g], ctx[g], lse[g])
+                recs[g].m = (h2[g], x2[g], m2[g], r2[g], u[g], a[g])
+                ss[g].layers.append(recs[g])
+        h = h3
+    out = []
+    for g in G:
+        st, s = sts[g], ss[g]
+        s.key_mask, s.causal = key_mask[g], causal
         # pooling (+ final LayerNorm)
         if c.kind == "vision":
             pl = torch.empty(N, d, **f32)
             mp, rp = torch.empty(N, **f32), torch.empty(N, **f32)
-            ops.layernorm_fwd(h, st.view("post_layernorm.weight"), st.view("post_layernorm.bias"), pl, mp, rp, N, d,
+            ops.layernorm_fwd(h[g], st.view("post_layernorm.weight"), st.view("post_layernorm.bias"), pl, mp, rp, N, d,
                               c.layer_norm_eps, in_mul=S)
             if Tf > 1:
                 pooled = torch.empty(B, d, **f32)
                 ops.mean_rows(pl, pooled, B, Tf, d)
             else:
                 pooled = pl
-            last = h.view(N, S, d)
-            s.pool = (h, mp, rp, None, None, None) if save else None
+            last = h[g].view(N, S, d)
+            s.pool = (h[g], mp, rp, None, None, None) if save else None
         else:
             last = torch.empty(rows, d, **f32)
             mf, rf = torch.empty(rows, **f32), torch.empty(rows, **f32)
             gw, gb = st.view("final_layer_norm.weight"), st.view("final_layer_norm.bias")
-            ops.layernorm_fwd(h, gw, gb, last, mf, rf, rows, d, c.layer_norm_eps)
+            ops.layernorm_fwd(h[g], gw, gb, last, mf, rf, rows, d, c.layer_norm_eps)
             eot = torch.empty(B, dtype=torch.int32, device=dev)
             ops.argmax_rows(s.ids, eot, B, S)
             pooled = torch.empty(B, d, **f32)
             mp, rp = torch.empty(B, **f32), torch.empty(B, **f32)
-            ops.layernorm_fwd(h, gw, gb, pooled, mp, rp, B, d, c.layer_norm_eps, in_mul=S, in_off=eot)
+            ops.layernorm_fwd(h[g], gw, gb, pooled, mp, rp, B, d, c.layer_norm_eps, in_mul=S, in_off=eot)
             last = last.view(B, S, d)
-            s.pool = (h, mp, rp, eot, mf, rf) if save else None
-        return s, last, pooled
+            s.pool = (h[g], mp, rp, eot, mf, rf) if save else None
+        out.append((s, last, pooled))
+    return out
 
-    # ------------------------------------------------------------------ backward implementation
-    def _linear_bwd(self, dy, x, wt, g_w, g_b, rows, dx_out=None, act=ops.ACT_NONE, aux_in=None):
-        """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result
-        STORED into the fp32 gradient - or ADDED to it when this backward accumulates, see _backward_impl); db += colsum(dy)
-        riding in the same GEMM (tail of the gradient buffer); dx = dy W through the transposed compute-dtype shadow (NT
-        form, vector epilogue)."""
-        ops.gemm(dy, x, g_w, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_b, accumulate=self._accumulate)
-        if dx_out is not None:
-            ops.gemm(dy, wt, dx_out, act=act, aux_in=aux_in, M=rows)
-        return dx_out
 
-    def _backward_impl(self, s, d_last, d_pooled):
-        c, st, T = self.config, self._store, self.compute_dtype
-        dev = st.master.device
-        d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
-        hd = d // H
-        B, Tf, N, S, rows = s.geom
-        # torch.autograd semantics for .grad: a backward ADDS to gradients that have not been consumed yet - a second
-        # micro-batch, the reference's teacher and student sharing one encoder, a tower called twice in a step.  "Consumed"
-        # = the engine's optimizer step ran (_grad_fresh cleared) or zero_grad(set_to_none=True) detached the views; after
-        # zero_grad(set_to_none=False) the buffers hold zeros, and adding to them is the same as storing.  In "autograd"
-        # gradient mode the values are handed to autograd, which does its own accumulation.
-        self._accumulate = bool(self._grad_fresh and _GRAD_MODE == "direct" and self._plist[0].grad is not None
-                                and st.grad is not None and self._plist[0].grad.data_ptr() == st.gview(self._param_names[0]).data_ptr())
-        if not self._accumulate:
-            st.zero_accumulated()
-        g = st.gview
-        f32 = dict(device=dev, dtype=torch.float32)
+def backward_lanes(towers, states, d_lasts, d_pooleds):
+    t0 = towers[0]
+    c, T = t0.config, t0.compute_dtype
+    G = range(len(towers))
+    sts = [t._store for t in towers]
+    dev = sts[0].master.device
+    d, f, H = c.hidden_size, c.intermediate_size, c.num_attention_heads
+    hd = d // H
+    B, Tf, N, S, rows = states[0].geom
+    for t in towers:
+        t._begin_backward()
+    if any(t._accumulate != t0._accumulate for t in towers):
+        raise RuntimeError("towers run in lock-step must agree on accumulating or overwriting their gradients")
+    f32 = dict(device=dev, dtype=torch.float32)
+    E = lambda *shape, **kw: [torch.empty(*shape, **kw) for _ in G]      # noqa: E731
+    tail = "post_layernorm" if c.kind == "vision" else "final_layer_norm"
+    dh, dh_T = [], E(rows, d, device=dev, dtype=T)
+    for g in G:
+        st, s, d_last, d_pooled = sts[g], states[g], d_lasts[g], d_pooleds[g]
+        gv = st.gview
         h_fin, mp, rp, eot, mf, rf = s.pool
         if d_last is not None and c.kind == "vision":
-            dh = d_last.reshape(rows, d).to(torch.float32).clone()
+            dhg = d_last.reshape(rows, d).to(torch.float32).clone()
         else:
-            dh = torch.zeros(rows, d, **f32)
-        tail = "post_layernorm" if c.kind == "vision" else "final_layer_norm"
+            dhg = torch.zeros(rows, d, **f32)
         gw = st.view(f"{tail}.weight")
         if d_pooled is not None:
             dp = d_pooled.to(torch.float32).contiguous()
-            ops.layernorm_bwd(dp, h_fin, mp, rp, gw, dh, g(f"{tail}.weight"), g(f"{tail}.bias"), N if c.kind == "vision" else B, d,
+            ops.layernorm_bwd(dp, h_fin, mp, rp, gw, dhg, gv(f"{tail}.weight"), gv(f"{tail}.bias"), N if c.kind == "vision" else B, d,
                               accumulate=True, dy_div=Tf if c.kind == "vision" else 1,
                               dy_scale=1.0 / Tf if c.kind == "vision" else 1.0, in_mul=S, in_off=eot)
         if d_last is not None and c.kind == "text":
             dl = d_last.reshape(rows, d).to(torch.float32).contiguous()
-            ops.layernorm_bwd(dl, h_fin, mf, rf, gw, dh, g(f"{tail}.weight"), g(f"{tail}.bias"), rows, d, accumulate=True)
-        dh_T = torch.empty(rows, d, device=dev, dtype=T)
-        ops.cast_rows(dh, dh_T, rows, d)
-        dact = ops.ACT_GRAD[ops.ACT_CODE[c.hidden_act]]
-        for i in reversed(range(c.num_hidden_layers)):
-            L = self._lp[i]
-            pfx = f"encoder.layers.{i}"
-            rec = s.layers[i]
-            # ---- MLP block: h3 = h2 + fc2(act(fc1(LN2(h2))))
-            h2, x2, m2, r2, u, a = rec.m
-            du = torch.empty(rows, f, device=dev, dtype=T)
-            self._linear_bwd(dh_T, a, self._w(f"{pfx}.fc2")[1], L.g_fc2_w, L.g_fc2_b, rows, dx_out=du, act=dact, aux_in=u)
-            dx2 = torch.empty(rows, d, device=dev, dtype=T)
-            self._linear_bwd(du, x2, self._w(f"{pfx}.fc1")[1], L.g_fc1_w, L.g_fc1_b, rows, dx_out=dx2)
-            ops.layernorm_bwd(dx2, h2, m2, r2, L.ln2_w, dh, L.g_ln2_w, L.g_ln2_b, rows, d, accumulate=True, dx_cast=dh_T)
-            # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
-            hin, x1, m1, r1, qkv, ctx, lse = rec.a
-            dctx = torch.empty(rows, d, device=dev, dtype=T)
-            self._linear_bwd(dh_T, ctx, self._w(f"{pfx}.out")[1], L.g_out_w, L.g_out_b, rows, dx_out=dctx)
-            dqkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
-            ops.attention_bwd(qkv, ctx, dctx, lse, dqkv, N, S, H, hd, causal=s.causal, key_mask=s.key_mask)
-            dx1 = torch.empty(rows, d, device=dev, dtype=T)
-            self._linear_bwd(dqkv, x1, self._w(f"{pfx}.qkv")[1], L.g_qkv_w, L.g_qkv_b, rows, dx_out=dx1)
-            ops.layernorm_bwd(dx1, hin, m1, r1, L.ln1_w, dh, L.g_ln1_w, L.g_ln1_b, rows, d, accumulate=True, dx_cast=dh_T)
-            if c.add_time_attn:
-                hin, xt, mt, rt, qkv, ctx, lse = rec.t
-                dctx = torch.empty(rows, d, device=dev, dtype=T)
-                self._linear_bwd(dh_T, ctx, self._w(f"{pfx}.tout")[1], L.g_tout_w, L.g_tout_b, rows, dx_out=dctx)
-                dqkv = torch.empty(rows, 3 * d, device=dev, dtype=T)
-                ops.attention_bwd(qkv, ctx, dctx, lse, dqkv, B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
-                dxt = torch.empty(rows, d, device=dev, dtype=T)
-                self._linear_bwd(dqkv, xt, self._w(f"{pfx}.tqkv")[1], L.g_tqkv_w, L.g_tqkv_b, rows, dx_out=dxt)
-                ops.layernorm_bwd(dxt, hin, mt, rt, L.tln_w, dh, L.g_tln_w, L.g_tln_b, rows, d, accumulate=True, dx_cast=dh_T)
+            ops.layernorm_bwd(dl, h_fin, mf, rf, gw, dhg, gv(f"{tail}.weight"), gv(f"{tail}.bias"), rows, d, accumulate=True)
+        ops.cast_rows(dhg, dh_T[g], rows, d)
+        dh.append(dhg)
+    dact = ops.ACT_GRAD[ops.ACT_CODE[c.hidden_act]]
+    W = lambda key, which: [t._w(key)[which] for t in towers]            # noqa: E731
+    for i in reversed(range(c.num_hidden_layers)):
+        L = [t._lp[i] for t in towers]
+        pfx = f"encoder.layers.{i}"
+        recs = [states[g].layers[i] for g in G]
+        # ---- MLP block: h3 = h2 + fc2(act(fc1(LN2(h2))))
+        h2, x2, m2, r2, u, a = (list(v) for v in zip(*[r.m for r in recs]))
+        du = E(rows, f, device=dev, dtype=T)
+        _linear_bwd_lanes(towers, dh_T, a, W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], rows, dx_outs=du, act=dact, aux_ins=u)
+        dx2 = E(rows, d, device=dev, dtype=T)
+        _linear_bwd_lanes(towers, du, x2, W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], rows, dx_outs=dx2)
+        for g in G:
+            ops.layernorm_bwd(dx2[g], h2[g], m2[g], r2[g], L[g].ln2_w, dh[g], L[g].g_ln2_w, L[g].g_ln2_b, rows, d, accumulate=True, dx_cast=dh_T[g])
+        # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
+        hin, x1, m1, r1, qkv, ctx, lse = (list(v) for v in zip(*[r.a for r in recs]))
+        dctx = E(rows, d, device=dev, dtype=T)
+        _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], rows, dx_outs=dctx)
+        dqkv = E(rows, 3 * d, device=dev, dtype=T)
+        for g in G:
+            ops.attention_bwd(qkv[g], ctx[g], dctx[g], lse[g], dqkv[g], N, S, H, hd, causal=states[g].causal, key_mask=states[g].key_mask)
+        dx1 = E(rows, d, device=dev, dtype=T)
+        _linear_bwd_lanes(towers, dqkv, x1, W(f"{pfx}.qkv", 1), [l.g_qkv_w for l in L], [l.g_qkv_b for l in L], rows, dx_outs=dx1)
+        for g in G:
+            ops.layernorm_bwd(dx1[g], hin[g], m1[g], r1[g], L[g].ln1_w, dh[g], L[g].g_ln1_w, L[g].g_ln1_b, rows, d, accumulate=True, dx_cast=dh_T[g])
+        if c.add_time_attn:
+            hin, xt, mt, rt, qkv, ctx, lse = (list(v) for v in zip(*[r.t for r in recs]))
+            dctx = E(rows, d, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.tout", 1), [l.g_tout_w for l in L], [l.g_tout_b for l in L], rows, dx_outs=dctx)
+            dqkv = E(rows, 3 * d, device=dev, dtype=T)
+            for g in G:
+                ops.attention_bwd(qkv[g], ctx[g], dctx[g], lse[g], dqkv[g], B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
+            dxt = E(rows, d, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, dqkv, xt, W(f"{pfx}.tqkv", 1), [l.g_tqkv_w for l in L], [l.g_tqkv_b for l in L], rows, dx_outs=dxt)
+            for g in G:
+                ops.layernorm_bwd(dxt[g], hin[g], mt[g], rt[g], L[g].tln_w, dh[g], L[g].g_tln_w, L[g].g_tln_b, rows, d, accumulate=True, dx_cast=dh_T[g])
                 if Tf != 1:
-                    ops.colsum(dh, L.g_temb, div=S, mod=Tf, R=rows)
-            s.layers[i] = None
-            if self._bucket_hook is not None and i % self.bucket_layers == 0:
-                # the weight-matrix gradients of layers i .. i+bucket_layers-1 are final (their kernels are enqueued): hand the
-                # range to the engine, whose all-reduce then travels while the layers below are still differentiating
-                self._bucket_hook(self, *self.layer_mat_range(i, min(i + self.bucket_layers, c.num_hidden_layers) - 1))
-        # ---- embeddings
-        if c.kind == "vision":
+                    ops.colsum(dh[g], L[g].g_temb, div=S, mod=Tf, R=rows)
+        for g in G:
+            states[g].layers[i] = None
+        if i % t0.bucket_layers == 0:
+            # the weight-matrix gradients of layers i .. i+bucket_layers-1 are final (their kernels are enqueued): hand the
+            # range to the engine, whose all-reduce then travels while the layers below are still differentiating
+            for t in towers:
+                if t._bucket_hook is not None:
+                    t._bucket_hook(t, *t.layer_mat_range(i, min(i + t.bucket_layers, c.num_hidden_layers) - 1))
+    # ---- embeddings
+    if c.kind == "vision":
+        P = S - 1
+        dpe = E(N * P, d, device=dev, dtype=T)
+        Us = []
+        for g in G:
+            st, s = sts[g], states[g]
+            gv = st.gview
             U, x0, m0, r0 = s.emb
             dx = torch.empty(rows, d, **f32)
-            ops.layernorm_bwd(dh, x0, m0, r0, st.view("pre_layrnorm.weight"), dx, g("pre_layrnorm.weight"), g("pre_layrnorm.bias"),
+            ops.layernorm_bwd(dh[g], x0, m0, r0, st.view("pre_layrnorm.weight"), dx, gv("pre_layrnorm.weight"), gv("pre_layrnorm.bias"),
                               rows, d, accumulate=False)
             # position-embedding gradient: sum over frames of dx[n, s, :] = a plain column sum of dx viewed as [N, S*d]
-            ops.colsum(dx.view(N, S * d), g("embeddings.position_embedding.weight").view(S * d), R=N)
-            ops.colsum(dx.view(N, S * d)[:, :d], g("embeddings.class_embedding"), R=N)
-            P = S - 1
-            dpe = torch.empty(N * P, d, device=dev, dtype=T)
-            ops.cast_rows(dx, dpe, N * P, d, rdiv=P, roff=1)
-            b = self._mat_blocks["patch"]
-            gwp = st.block_view(b, st.grad).view(d, b.numel // d)
-            self._linear_bwd(dpe, U, None, gwp, None, N * P)
-        else:
-            ops.token_embed_bwd(s.ids, dh, g("embeddings.token_embedding.weight"), g("embeddings.position_embedding.weight"), B, S, d)
-
-    def attach_grads(self):
-        """p.grad of every parameter = its view into the flat gradient buffer.  Runs after every backward on the host thread
-        that feeds the GPU, so the (parameter, view) pairs are resolved once: walking ~200 dotted names per call cost 0.7 ms,
-        during which the stream of the following tower's backward sat empty."""
-        st = self._store
-        grad = st.ensure_grad()
-        cache = self._grad_cache
-        if cache is None or cache[0] is not grad:
-            cache = self._grad_cache = (grad, [(self.get_parameter(n), st.gview(n)) for n in self._param_names])
-        for p, gv in cache[1]:
-            if p.grad is not gv:
-                p.grad = gv
+            ops.colsum(dx.view(N, S * d), gv("embeddings.position_embedding.weight").view(S * d), R=N)
+            ops.colsum(dx.view(N, S * d)[:, :d], gv("embeddings.class_embedding"), R=N)
+            ops.cast_rows(dx, dpe[g], N * P, d, rdiv=P, roff=1)
+            Us.append(U)
+        gwp = []
+        for t in towers:
+            b = t._mat_blocks["patch"]
+            gwp.append(t._store.block_view(b, t._store.grad).view(d, b.numel // d))
+        _linear_bwd_lanes(towers, dpe, Us, None, gwp, None, N * P)
+    else:
+        st, s = sts[0], states[0]
+        ops.token_embed_bwd(s.ids, dh[0], st.gview("embeddings.token_embedding.weight"), st.gview("embeddings.position_embedding.weight"), B, S, d)
 
 
 class _TowerFn(torch.autograd.Function):
@@ -615,3 +696,45 @@ class _TowerFn(torch.autograd.Function):
             return (None, None, None, None) + grads
         tower.attach_grads()
         return (None, None, None, None)
+
+
+class _TowerGroupFn(torch.autograd.Function):
+    """several shape-identical towers as ONE autograd node: forward and backward run in lock-step (forward_lanes / backward_lanes)"""
+
+    @staticmethod
+    def forward(ctx, anchor, towers, inputs, need_grad):
+        outs = forward_lanes(towers, inputs, save=need_grad)
+        ctx.towers, ctx.states = towers, [o[0] for o in outs]
+        flat = []
+        for _, last, pooled in outs:
+            flat += [last, pooled]
+        return tuple(flat)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        towers, states = ctx.towers, ctx.states
+        if states is None or not states[0].save:
+            raise RuntimeError("tower-group backward called twice or without saved activations")
+        ctx.states = None
+        backward_lanes(towers, states, list(grads[0::2]), list(grads[1::2]))
+        for t in towers:
+            t._grad_fresh = True
+            if t._post_backward is not None:
+                t._post_backward(t)
+            t.attach_grads()
+        return (None, None, None, None)
+
+
+def run_towers(towers, kwargs_list):
+    """[(last_hidden_state, pooled_output)] of `towers[i](**kwargs_list[i])`; shape-identical vision towers run in lock-step with
+    grouped GEMM launches (one tile grid for all of them), anything else one after the other - same results either way."""
+    inputs = [(kw.get("pixel_values"),) for kw in kwargs_list]
+    grouped = (len(towers) > 1 and _GRAD_MODE == "direct" and all(i[0] is not None for i in inputs) and lanes_compatible(towers, inputs)
+               and len({id(t) for t in towers}) == len(towers))
+    if not grouped:
+        return [t(**kw) for t, kw in zip(towers, kwargs_list)]
+    for t in towers:
+        t._ensure_ready()
+    need_grad = torch.is_grad_enabled() and any(p.requires_grad for t in towers for p in t.parameters())
+    flat = _TowerGroupFn.apply(towers[0]._anchor, list(towers), inputs, need_grad)
+    return [(flat[2 * i], flat[2 * i + 1]) for i in range(len(towers))]

@@ -324,3 +324,46 @@ def test_eager_engine_rejects_second_backward(pkg):
     _, p = tower(x)
     p.sum().backward()                                              # a new step is fine again
     eng.step()
+
+
+def test_lockstep_tower_groups_equal_separate_towers(pkg):
+    """image / audio / depth towers (one config, one input shape) run in lock-step with grouped GEMM launches (one tile grid for
+    the three of them, forward, dX and dW); the result must be what the towers give one after the other - and what the oracle
+    gives for two of the samples."""
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    mods = ["image", "audio", "depth"]
+    T = pkg.towers.TowerConfig
+    enc = pkg.lb.LanguageBind({m: f"LanguageBind_{m.capitalize()}" for m in mods}, configs={m: T(kind="vision") for m in mods},
+                              compute_dtype=torch.bfloat16, seed=11)
+    args = types.SimpleNamespace(modality_types=mods, feature_dims=768, fusion_dim=256, dropout_prob=0.0, fusion_type="sum")
+    torch.manual_seed(0)
+    model = pkg.base.finetune_model(args, 8, enc)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model = model.cuda()
+    B = 32
+    g = torch.Generator().manual_seed(3)
+    data = {m: {"pixel_values": torch.randn(B, 3, 224, 224, generator=g)} for m in mods}
+    labels = torch.randint(0, 8, (B,), generator=g)
+    missing = torch.zeros(B, dtype=torch.int64)
+    missing[1], missing[5] = pkg.base.missing_type_index["audio"], pkg.base.missing_type_index["depth"]
+    gdata = _to_gpu(data)
+    names = [f"encoder.modality_encoder.{m}.{k}" for m in mods for k in
+             ("encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.7.mlp.fc1.weight", "encoder.layers.11.mlp.fc2.bias",
+              "embeddings.patch_embedding.weight", "encoder.layers.3.layer_norm1.weight")]
+    runs = {}
+    for grouped in (True, False):
+        enc.group_towers = grouped
+        assert len(enc._units(gdata)) == (1 if grouped else 3)
+        model.zero_grad(set_to_none=True)
+        logits = model(gdata, missing.cuda())
+        HipCrossEntropyLoss()(logits, labels.cuda()).backward()
+        runs[grouped] = (logits.detach().clone(), {k: model.get_parameter(k).grad.clone() for k in names})
+    assert rel(runs[True][0], runs[False][0]) < 2e-3
+    for k in names:
+        assert grad_ok(k, runs[True][1][k], runs[False][1][k], 1e-2, torch.bfloat16), k
+    # two samples against the CPU oracle (batch-independent rows of the B = 32 lock-step run)
+    idx = torch.tensor([0, 1])
+    tp, ocfg, proj, scales, fp = _oracle_parts(sd, mods)
+    with torch.no_grad():
+        ologits, _ = O.finetune_forward({m: {"pixel_values": data[m]["pixel_values"][idx]} for m in mods}, missing[idx], tp, ocfg, proj, scales, fp, mods)
+    assert rel(runs[True][0][:2], ologits) < 5e-2

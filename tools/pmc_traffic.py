@@ -4,7 +4,7 @@ both counters are in KiB.  Usage: pmc_traffic.py <fetch counter_collection.csv> 
 import json, sys
 import pandas as pd
 
-FAMILIES = (("gemm", ("gemm_kernel", "splitk_reduce")), ("ln", ("ln_fwd", "ln_bwd")), ("attn", ("attn_",)), ("adam", ("adam_kernel", "adam_cast_batched")))
+FAMILIES = (("gemm", ("gemm_kernel", "gemm8p", "splitk_reduce")), ("ln", ("ln_fwd", "ln_bwd")), ("attn", ("attn_",)), ("adam", ("adam_kernel", "adam_cast_batched")))
 
 
 def family(name):
@@ -17,7 +17,7 @@ def family(name):
 def load(path, counter):
     d = pd.read_csv(path)
     d = d[d.Counter_Name == counter]
-    d = d.assign(fam=d.Kernel_Name.map(family), is_gemm=d.Kernel_Name.str.contains("gemm_kernel"))
+    d = d.assign(fam=d.Kernel_Name.map(family), is_gemm=d.Kernel_Name.str.contains("gemm_kernel|gemm8p_kernel|gemm8p_tn_kernel"))
     return d
 
 
