@@ -185,6 +185,13 @@ int missm_kl_loss(const float* student, const float* teacher, const unsigned cha
 int missm_mse_loss(const float* a, const float* b, float* loss, float* da, long n, void* stream);
 /* teacher EMA of the MTD student mode (train_ddp.py:256-259): teacher = decay * teacher + (1 - decay) * student. */
 int missm_ema_update(float* teacher, const float* student, long n, float decay, void* stream);
+/* GPU-side preprocessing of ONE decoded image (reference image/processing_image.py:18-28, thermal/processing_thermal.py:18-28:
+ * ToTensor, Resize(S, bicubic) of the shorter edge, CenterCrop(S), Normalize; depth/processing_depth.py:21-55: DepthNorm first).
+ * src: uint8 or float32 (src_u8), [C,H,W] (chw) or [H,W,C], C = 1 (replicated to 3 channels) or 3, DEVICE memory (pinned-staged
+ * by the caller).  v = clip(v * pre_scale, pre_min, pre_max) / pre_div before resampling (pre_max <= 0: no upper clip):
+ * images 1/255, -inf.., 1 ; depth 1/1000, 0.01, max_depth, max_depth.  dst: fp32 [3, S, S].  mean3 / std3: HOST arrays. */
+int missm_preprocess_image(const void* src, int src_u8, int chw, int H, int W, int C, float* dst, int S, float pre_scale, float pre_min,
+                           float pre_max, float pre_div, const float* mean3, const float* std3, void* stream);
 /* inverted dropout with a counter-based generator: y = x * mask / (1-p); mask saved as bytes (src/model/baseline.py:34). */
 int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream);
 int missm_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, void* stream);

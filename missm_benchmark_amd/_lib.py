@@ -44,6 +44,7 @@ SIGNATURES = {
     "missm_kl_loss": [P, P, P, P, P, I, I, F, P],
     "missm_mse_loss": [P, P, P, P, L, P],
     "missm_ema_update": [P, P, L, F, P],
+    "missm_preprocess_image": [P, I, I, I, I, I, P, I, F, F, F, F, P, P, P],
     "missm_dropout_fwd": [P, P, P, L, F, U64, P],
     "missm_dropout_bwd": [P, P, P, L, F, P],
     "missm_adam_step": [P, P, P, P, L, I, F, F, F, F, F, F, P],
@@ -52,7 +53,7 @@ SIGNATURES = {
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
-ABI_VERSION = 5     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 6     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

@@ -64,8 +64,12 @@ template <bool PW> __device__ __forceinline__ void stage_wait() {
 // PW = false: one workgroup (8 waves) per (sequence, head), tiles dealt over the waves  (S = 197 / 77)
 // PW = true : one WAVE per (sequence, head) with its own LDS slice, no workgroup barrier (time attention, L = T <= 32):
 //             the 8x8 score block rides in one 16x16 MFMA tile; 6 MFMAs per unit instead of ~2000 VALU FMAs per lane.
-template <typename T, int NTP, bool PW, bool CAUSAL>
-__global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) {
+// MASK: the additive key bias (key_padding_mask / padded keys, -inf) is applied to every key tile; otherwise only to the last two.
+// FULL: the host guarantees L > 16 (NTP - 2): every key tile but the last two holds 16 keys, so the bulk of the tile loop carries
+//       no run-time condition at all (the conditions cost more than they saved: 145 branches, 150 waits and ~130 register
+//       zero-fills per query tile in the first conditional version - the kernel is VALU-issue-bound).
+template <typename T, int NTP, bool PW, bool CAUSAL, bool MASK = true, bool FULL = false>
+__global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_fwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
@@ -118,49 +122,76 @@ __global__ __launch_bounds__(ATHREADS, 4) void attn_fwd_mfma_kernel(AttnArgs a) 
     const bool qvalid = qi < L;
     const size_t qrow = base + (size_t)(qvalid ? qi : 0) * a.tok_stride;
     Frag (&qf)[KSQ] = qfa[t];
+    // The kernel is VALU-issue-bound (the exp2 alone is 2 of ~7.5 issue slots per score in the first version, 56 MFMAs per 16
+    // queries against ~450 VALU instructions), so everything that is not the exp2 is kept off the VALU where possible:
+    //  * key tiles that hold no key at all (L = 197 pads to 14 tiles of 16, the 14th is empty) are neither multiplied nor
+    //    exponentiated: their probabilities are literal zeros;
+    //  * the additive key bias (padding / key_padding_mask, -inf) is applied only where a tile can hold a masked key;
+    //  * the row maximum runs over the RAW accumulators as v_max3 (two scores per instruction), the softmax scale and the
+    //    maximum meet in ONE fused multiply-add in front of the exp2: p = exp2(s * scale * log2e - max * scale * log2e);
+    //  * the row sum is one more row of the PV product (a ones-row appended to V^T: 7 MFMAs on the idle matrix pipe instead
+    //    of 56 adds), taken from the SAME rounded probabilities that multiply V;
+    //  * fragment addresses are lane constants + immediates (the swizzle key of row 16 kt + li is li & 7 for every kt).
+    const int nkt = (L + 15) >> 4;            // key tiles that hold at least one key
+    constexpr int NFULL = (FULL && !PW) ? NTP - 2 : 0;
+    int koff[KSQ];
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) koff[ks] = swz<RBv>(li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
     f32x4 p[NTP];
     float mx = kNegInf;
 #pragma unroll
     for (int kt = 0; kt < NTP; ++kt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      if (kt < NFULL || kt < nkt) {           // (compile-time true for the full tiles)
+        f32x4 acc = M_::step(lds_frag<T>(ldsK + kt * 16 * RBv, koff[0]), qf[0], f32x4{0.f, 0.f, 0.f, 0.f});
 #pragma unroll
-      for (int ks = 0; ks < KSQ; ++ks)
-        acc = M_::step(lds_frag<T>(ldsK, swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T))), qf[ks], acc);
-      // scores live in the log2 domain (scale * log2(e) folded into one multiply-add: exp2 is the hardware instruction), and
-      // the causal select is compiled in only for the text tower (template flag): the kernel is VALU-issue-bound (~520 VALU vs 56 MFMA per tile)
-      const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+        for (int ks = 1; ks < KSQ; ++ks) acc = M_::step(lds_frag<T>(ldsK + kt * 16 * RBv, koff[ks]), qf[ks], acc);
+        if (MASK || kt >= NFULL) acc += *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+        if constexpr (CAUSAL) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float s = acc[r] * sl2 + kb[r];
-        if constexpr (CAUSAL) { if (kt * 16 + 4 * lg + r > qi) s = kNegInf; }
-        p[kt][r] = s;
-        mx = fmaxf(mx, s);
+          for (int r = 0; r < 4; ++r) if (kt * 16 + 4 * lg + r > qi) acc[r] = kNegInf;
+        }
+        mx = fmaxf(fmaxf(mx, acc[0]), acc[1]);           // v_max3_f32
+        mx = fmaxf(fmaxf(mx, acc[2]), acc[3]);
+        p[kt] = acc;
+      } else {
+        p[kt] = f32x4{kNegInf, kNegInf, kNegInf, kNegInf};
       }
     }
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (mx == kNegInf) mx = 0.f;
-    float sum = 0.f;
+    const float mxs = mx * sl2;
 #pragma unroll
     for (int kt = 0; kt < NTP; ++kt)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) { p[kt][r] = __builtin_amdgcn_exp2f(p[kt][r] - mx); sum += p[kt][r]; }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
-    const float inv = 1.0f / sum;
-    if (a.lse && qvalid && lg == 0) a.lse[((size_t)seq * a.H + h) * L + qi] = (mx + __log2f(sum)) * 0.6931471805599453f;
-
-    Frag pf[NU];
+      for (int r = 0; r < 4; ++r) p[kt][r] = __builtin_amdgcn_exp2f(p[kt][r] * sl2 - mxs);    // (empty tiles: exp2(-inf) = 0)
+    // PV with the key steps OUTSIDE: a probability fragment is packed, used for the four 16-wide slices of the head (+ the
+    // ones-row: O^T gets a 65th row from a V^T row of ones, whose A operand is a constant) and dropped - nothing but the five
+    // accumulators lives across steps (the fp32 instantiation spilled 888 bytes per lane holding all fragments).
+    Frag ones = M_::zero();
+    if (li == 0) {
 #pragma unroll
-    for (int u = 0; u < NU; ++u) pf[u] = M_::from_acc(p[u * M_::CTILES], p[u * M_::CTILES + M_::CTILES - 1]);
+      for (int j = 0; j < M_::KPL; ++j) ones[j] = (T)1.0f;
+    }
+    f32x4 oacc[HD / 16], sacc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) oacc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      if (!(u * M_::CTILES < NFULL || u * M_::CTILES < nkt)) continue;      // (wave-uniform) a step whose key tiles are all empty
+      const Frag pf = M_::from_acc(p[u * M_::CTILES], p[u * M_::CTILES + M_::CTILES - 1]);
+      sacc = M_::step(ones, pf, sacc);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) oacc[dt] = M_::step(TrFrag<T, RBv>::load(ldsV, u * M_::KS, dt * 16, lane), pf, oacc[dt]);
+    }
+    const float sum = __shfl(sacc[0], li, 64);   // row 0 of the ones tile lives in register 0 of the lanes with lg == 0
+    const float inv = 1.0f / sum;
+    if (a.lse && qvalid && lg == 0) a.lse[((size_t)seq * a.H + h) * L + qi] = (mxs + __log2f(sum)) * 0.6931471805599453f;
     T* out = static_cast<T*>(a.out);
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < NU; ++u) acc = M_::step(TrFrag<T, RBv>::load(ldsV, u * M_::KS, dt * 16, lane), pf[u], acc);
-      acc *= inv;
-      if (qvalid) store4(out + qrow * a.ldo + h * HD + dt * 16 + 4 * lg, acc);
+      oacc[dt] *= inv;
+      if (qvalid) store4(out + qrow * a.ldo + h * HD + dt * 16 + 4 * lg, oacc[dt]);
     }
   }
 }
@@ -208,14 +239,16 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
   const T* fout = static_cast<const T*>(a.out);
   T* dqkv = static_cast<T*>(a.dqkv);
   const int L = a.L;
-  const float sl2 = a.scale * 1.4426950408889634f;   // scale * log2(e); lse is rescaled to the log2 domain on its way into LDS
+  const float sl2 = a.scale * 1.4426950408889634f;   // scale * log2(e)
+  const float inv_scale = 1.0f / a.scale;             // lse / scale goes into LDS: it is the score accumulators' initial value
   const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
+  const bool any_mask = a.key_mask != nullptr;
 
   stage_head<T, RBv, NWV>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wv);
   stage_head<T, RBv, NWV>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, lane, wv);
   for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS) {
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
-    lseL[k] = k < L ? lse[k] * 1.4426950408889634f : __builtin_huge_valf();
+    lseL[k] = k < L ? lse[k] * inv_scale : __builtin_huge_valf();
   }
   const int nt = (L + 15) / 16;
   constexpr int MAXQ = (NTP + NWV - 1) / NWV;   // query / key tiles per wave
@@ -277,40 +310,46 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
     } else {
       (void)load_q(qt, qf, dof);
     }
-    const float lq = lseL[qi];
-    const float dsum = dsa[t];
-    Frag dsf[NU];
+    // Row constants ride in as the INITIAL accumulators (the kernel is VALU-issue-bound): S' = q.k - lse / scale and
+    // dP' = dO.v - D leave the MFMA chains ready, p = exp2(S' * scale * log2e) needs no subtraction, dS = p * dP' no difference.
+    // An out-of-range query has lse = +inf: S' = -inf, p = 0.  Key tiles without any key are skipped (dS = 0).
+    const float nlq = -lseL[qi];
+    const float ndsum = -dsa[t];
+    f32x4 dqa[HD / 16];                       // dQ^T of this query tile: accumulated key step by key step (no fragment array)
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) dqa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
+      if (u * CT >= nt) continue;             // (wave-uniform) no key in this step
       f32x4 dsv[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int kt = u * CT + c;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (kt >= nt) { dsv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+        f32x4 sc = {nlq, nlq, nlq, nlq}, dp = {ndsum, ndsum, ndsum, ndsum};
 #pragma unroll
         for (int ks = 0; ks < KSQ; ++ks) {
           const int off = swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
           sc = M_::step(lds_frag<T>(X0, off), qf[ks], sc);
           dp = M_::step(lds_frag<T>(X1, off), dof[ks], dp);
         }
-        const f32x4 kb = *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+        if (any_mask || kt * 16 + 16 > L) sc += *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);   // (-inf on masked keys)
         // (the softmax scale is applied once to the dQ / dK accumulators instead of to every dS element)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kb[r] - lq);
+          float pv = __builtin_amdgcn_exp2f(sc[r] * sl2);
           if constexpr (CAUSAL) { if (kt * 16 + 4 * lg + r > qi) pv = 0.f; }
-          dsv[c][r] = pv * (dp[r] - dsum);
+          dsv[c][r] = pv * dp[r];
         }
       }
-      dsf[u] = M_::from_acc(dsv[0], dsv[CT - 1]);
+      const Frag dsf = M_::from_acc(dsv[0], dsv[CT - 1]);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) dqa[dt] = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf, dqa[dt]);
     }
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < NU; ++u) acc = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf[u], acc);
-      acc *= a.scale;
-      if (qvalid) store4(dqkv + qrow * a.ld + h * HD + dt * 16 + 4 * lg, acc);
+      dqa[dt] *= a.scale;
+      if (qvalid) store4(dqkv + qrow * a.ld + h * HD + dt * 16 + 4 * lg, dqa[dt]);
     }
   }
   if constexpr (!PW) __syncthreads();
@@ -354,46 +393,50 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
         }
       }
     }
-    const float kb = kbias[key];
-    Frag pf[NU], dsf[NU];
+    const bool use_kb = any_mask || kt * 16 + 16 > L;      // wave-uniform: this wave's key tile may hold a masked / padded key
+    const float kb = use_kb ? kbias[key] : 0.f;
+    f32x4 dva[HD / 16], dka[HD / 16];          // dV^T / dK^T of this key tile, accumulated query step by query step
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) { dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dka[dt] = dva[dt]; }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
+      if (u * CT >= nt) continue;             // (wave-uniform) no query in this step
       f32x4 pv4[CT], dsv[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int qt = u * CT + c;
-        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        if (qt >= nt) { pv4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dsv[c] = pv4[c]; continue; }     // query tile without any query
+        // initial accumulators: -lse / scale and -D of the tile's 4 query rows this lane holds (see pass A)
+        f32x4 sc = -*reinterpret_cast<const f32x4*>(lseL + qt * 16 + 4 * lg);
+        f32x4 dp = -*reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
 #pragma unroll
         for (int ks = 0; ks < KSQ; ++ks) {
           const int off = swz<RBv>(qt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
           sc = M_::step(lds_frag<T>(X0, off), kf[ks], sc);
           dp = M_::step(lds_frag<T>(X1, off), vf[ks], dp);
         }
-        const f32x4 lq = *reinterpret_cast<const f32x4*>(lseL + qt * 16 + 4 * lg);
-        const f32x4 dq = *reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kb - lq[r]);
+          float pv = __builtin_amdgcn_exp2f(use_kb ? sc[r] * sl2 + kb : sc[r] * sl2);
           if constexpr (CAUSAL) { if (key > qt * 16 + 4 * lg + r) pv = 0.f; }
           pv4[c][r] = pv;
-          dsv[c][r] = pv * (dp[r] - dq[r]);
+          dsv[c][r] = pv * dp[r];
         }
       }
-      pf[u] = M_::from_acc(pv4[0], pv4[CT - 1]);
-      dsf[u] = M_::from_acc(dsv[0], dsv[CT - 1]);
+      const Frag pf = M_::from_acc(pv4[0], pv4[CT - 1]);
+      const Frag dsf = M_::from_acc(dsv[0], dsv[CT - 1]);
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        dva[dt] = M_::step(TrFrag<T, RBv>::load(X1, u * M_::KS, dt * 16, lane), pf, dva[dt]);
+        dka[dt] = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf, dka[dt]);
+      }
     }
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) {
-      f32x4 dv = {0.f, 0.f, 0.f, 0.f}, dk = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        dv = M_::step(TrFrag<T, RBv>::load(X1, u * M_::KS, dt * 16, lane), pf[u], dv);
-        dk = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf[u], dk);
-      }
-      dk *= a.scale;
+      dka[dt] *= a.scale;
       if (kin) {
-        store4(dqkv + krow * a.ld + a.d + h * HD + dt * 16 + 4 * lg, dk);
-        store4(dqkv + krow * a.ld + 2 * a.d + h * HD + dt * 16 + 4 * lg, dv);
+        store4(dqkv + krow * a.ld + a.d + h * HD + dt * 16 + 4 * lg, dka[dt]);
+        store4(dqkv + krow * a.ld + 2 * a.d + h * HD + dt * 16 + 4 * lg, dva[dt]);
       }
     }
   }
@@ -629,13 +672,25 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
   }
   if (hd != HD || L > 256) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64 and L<=256)", L, hd); return MISSM_ERR_INVALID; }
   dim3 grid(a.nseq * a.H), block(ATHREADS);
+  // forward specialisations: FULL when every key tile but the last two is full (L > 16 (NTP - 2): S = 197 / NTP 14, S = 77 / NTP 6),
+  // MASK when a key_padding_mask (or causality, which always comes with one here) can hit any tile
+  const bool mask = a.key_mask != nullptr || a.causal;
 #define MISSM_MFMA(NTP)                                                                                     \
   do {                                                                                                      \
     size_t shmem = (size_t)2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1);              \
-    auto k = a.causal ? (BWD ? attn_bwd_mfma_kernel<T, NTP, false, true> : attn_fwd_mfma_kernel<T, NTP, false, true>)     \
-                      : (BWD ? attn_bwd_mfma_kernel<T, NTP, false, false> : attn_fwd_mfma_kernel<T, NTP, false, false>); \
-    int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                            \
-    hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                         \
+    const bool full = L > 16 * (NTP - 2);                                                                   \
+    if constexpr (BWD) {                                                                                    \
+      auto k = a.causal ? attn_bwd_mfma_kernel<T, NTP, false, true> : attn_bwd_mfma_kernel<T, NTP, false, false>;          \
+      int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                          \
+      hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                       \
+    } else {                                                                                                \
+      auto k = (full && !mask) ? attn_fwd_mfma_kernel<T, NTP, false, false, false, true>                       \
+               : (full && a.causal) ? attn_fwd_mfma_kernel<T, NTP, false, true, true, true>                    \
+               : a.causal ? attn_fwd_mfma_kernel<T, NTP, false, true, true, false>                             \
+                          : attn_fwd_mfma_kernel<T, NTP, false, false, true, false>;                           \
+      int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                          \
+      hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                       \
+    }                                                                                                       \
   } while (0)
   if (L <= 96) MISSM_MFMA(6); else if (L <= 224) MISSM_MFMA(14); else MISSM_MFMA(16);
 #undef MISSM_MFMA

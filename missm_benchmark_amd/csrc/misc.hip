@@ -138,28 +138,41 @@ __device__ __forceinline__ float eff_dy(const float* dy, int lddy, const float* 
   return g;
 }
 
-// dx[b, i] (+)= sum_o dyeff[b, o] w[o, i].  One thread per element, the whole reduction over o in a FIXED order (four
-// interleaved partial sums, combined pairwise): the result is bit-reproducible from run to run.  (The first version split o
-// over blockIdx.y and met in fp32 atomics; the arrival order changed the last bits of the gradient that enters the towers, and
-// their bf16 backward amplifies a 1-ulp difference into 1e-3-level differences of the weight gradients.)
-__global__ __launch_bounds__(256) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+// dx[b, i] (+)= sum_o dyeff[b, o] w[o, i].  One workgroup per (sample, 64 inputs): its 8 waves take an eighth of the outputs
+// each (lane = input column: the weight rows are read coalesced), four interleaved partial sums per lane, and the 8 partials
+// meet in LDS in a FIXED order - the result is bit-reproducible from run to run.  (The first version split o over blockIdx.y
+// and met in fp32 atomics: the arrival order changed the last bits of the gradient that enters the towers, and their bf16
+// backward amplifies a 1-ulp difference into 1e-3-level differences of the weight gradients.  One thread per element with the
+// whole reduction in a loop is reproducible too, but latency-bound: 153 us per call at O = 768.)
+__global__ __launch_bounds__(512) void small_linear_dx_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                              const float* __restrict__ relu_y, float* __restrict__ dx, int B, int I, int O,
                                                              int lddy, const long* __restrict__ row_code, long code, int select, float alpha,
                                                              int accumulate) {
-  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= (long)B * I) return;
-  const int b = idx / I, i = idx % I;
+  __shared__ float part[8][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.y, i = blockIdx.x * 64 + lane;
+  const int per = (O + 7) / 8, o0 = wave * per, o1 = min(O, o0 + per);
   float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int o = 0;
-  for (; o + 3 < O; o += 4) {
-    a0 += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
-    a1 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 1, O, select) * w[(long)(o + 1) * I + i];
-    a2 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 2, O, select) * w[(long)(o + 2) * I + i];
-    a3 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 3, O, select) * w[(long)(o + 3) * I + i];
+  if (i < I) {
+    int o = o0;
+    for (; o + 3 < o1; o += 4) {
+      a0 += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
+      a1 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 1, O, select) * w[(long)(o + 1) * I + i];
+      a2 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 2, O, select) * w[(long)(o + 2) * I + i];
+      a3 += eff_dy(dy, lddy, relu_y, row_code, code, b, o + 3, O, select) * w[(long)(o + 3) * I + i];
+    }
+    for (; o < o1; ++o) a0 += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
   }
-  for (; o < O; ++o) a0 += eff_dy(dy, lddy, relu_y, row_code, code, b, o, O, select) * w[(long)o * I + i];
-  const float acc = ((a0 + a1) + (a2 + a3)) * alpha;
-  dx[idx] = accumulate ? dx[idx] + acc : acc;
+  part[wave][lane] = (a0 + a1) + (a2 + a3);
+  __syncthreads();
+  if (wave == 0 && i < I) {
+    float acc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc += part[k][lane];
+    acc *= alpha;
+    const long idx = (long)b * I + i;
+    dx[idx] = accumulate ? dx[idx] + acc : acc;
+  }
 }
 
 // dw[o, i] = sum_b dyeff[b, o] x[b, i] ; dbias[o] = sum_b dyeff[b, o]
@@ -317,6 +330,73 @@ __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tea, const
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) tea[i] = tea[i] * decay + stu[i] * (1.f - decay);
 }
 
+
+// ---- GPU-side image / depth preprocessing (reference processing_image.py:18-28, processing_thermal.py:18-28, processing_depth.py:21-55) ----
+// One launch turns a decoded image into the tower's pixel_values: ToTensor (u8 -> [0,1]) or DepthNorm (/1000, clip, / max_depth),
+// Resize(S, bicubic) of the SHORTER edge, CenterCrop(S), Normalize(mean, std) - only the S x S pixels that survive the crop are
+// ever computed.  The resampling is torchvision's tensor path = ATen's antialiased bicubic (separable cubic with a = -0.5, the
+// support stretched by the down-scaling factor, weights normalised to 1): restated from the published algorithm
+// (aten/src/ATen/native/UpSampleBicubic2d / "_upsample_bicubic2d_aa"); torchvision is absent here, so parity is unpinned.
+struct PrepArgs {
+  const void* src; float* dst;
+  int src_u8, chw, H, W, C;          // source: uint8 or float32; [C,H,W] or [H,W,C]; C = 1 (replicated) or 3
+  int new_h, new_w, top, left, S;    // resized size, crop origin, output edge
+  float pre_scale, pre_min, pre_max, pre_div;   // v = clip(v * pre_scale, pre_min, pre_max) / pre_div   (pre_max <= 0: no upper clip)
+  float mean[3], inv_std[3];
+};
+__device__ __forceinline__ float cubic_aa(float x) {   // a = -0.5 (the antialiased path's filter)
+  x = fabsf(x);
+  if (x < 1.f) return ((1.5f * x - 2.5f) * x) * x + 1.f;
+  if (x < 2.f) return (((x - 5.f) * x + 8.f) * x - 4.f) * -0.5f;
+  return 0.f;
+}
+__device__ __forceinline__ void aa_window(int i, float scale, int in_size, int& xmin, int& xsize, float& center, float& invscale) {
+  const float support = scale >= 1.f ? 2.f * scale : 2.f;
+  invscale = scale >= 1.f ? 1.f / scale : 1.f;
+  center = scale * (i + 0.5f);
+  xmin = max(0, (int)(center - support + 0.5f));
+  xsize = min(in_size, (int)(center + support + 0.5f)) - xmin;
+}
+__global__ __launch_bounds__(256) void preprocess_image_kernel(PrepArgs a) {
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= a.S * a.S) return;
+  const int oy = idx / a.S, ox = idx % a.S;
+  const float sh = (float)a.H / (float)a.new_h, sw = (float)a.W / (float)a.new_w;
+  int ymin, ysize, xmin, xsize; float cy, cx, isy, isx;
+  aa_window(oy + a.top, sh, a.H, ymin, ysize, cy, isy);
+  aa_window(ox + a.left, sw, a.W, xmin, xsize, cx, isx);
+  float wys = 0.f, wxs = 0.f;
+  for (int j = 0; j < ysize; ++j) wys += cubic_aa((j + ymin - cy + 0.5f) * isy);
+  for (int i = 0; i < xsize; ++i) wxs += cubic_aa((i + xmin - cx + 0.5f) * isx);
+  float acc[3] = {0.f, 0.f, 0.f};
+  for (int j = 0; j < ysize; ++j) {
+    const float wy = cubic_aa((j + ymin - cy + 0.5f) * isy) / wys;
+    const int y = ymin + j;
+    float row[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < xsize; ++i) {
+      const float wx = cubic_aa((i + xmin - cx + 0.5f) * isx) / wxs;
+      const int x = xmin + i;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        if (c >= a.C) break;
+        const size_t off = a.chw ? ((size_t)c * a.H + y) * a.W + x : ((size_t)y * a.W + x) * a.C + c;
+        float v = a.src_u8 ? (float)static_cast<const unsigned char*>(a.src)[off] : static_cast<const float*>(a.src)[off];
+        v *= a.pre_scale;
+        v = fmaxf(v, a.pre_min);
+        if (a.pre_max > 0.f) v = fminf(v, a.pre_max);
+        row[c] += wx * (v / a.pre_div);
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc[c] += wy * row[c];
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    const float v = a.C == 1 ? acc[0] : acc[c];
+    a.dst[((size_t)c * a.S + oy) * a.S + ox] = (v - a.mean[c]) * a.inv_std[c];
+  }
+}
+
 __device__ __forceinline__ uint32_t hash_u64(unsigned long long x) {  // splitmix64 finaliser
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -446,7 +526,7 @@ extern "C" int missm_small_linear_bwd(const float* dy, int lddy, const float* x,
   MISSM_CHECK_ARG(!relu_y || lddy == O, "small_linear_bwd: the relu mask is dense, dy must be too");
   MISSM_CHECK_ARG(!relu_y || alpha == 1.0f, "small_linear_bwd: alpha with a fused ReLU is not supported");
   if (dx) {
-    hipLaunchKernelGGL(small_linear_dx_kernel, dim3(((long)B * I + 255) / 256), dim3(256), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, alpha, accumulate_dx);
+    hipLaunchKernelGGL(small_linear_dx_kernel, dim3((I + 63) / 64, B), dim3(512), 0, S_(stream), dy, w, relu_y, dx, B, I, O, lddy, row_code, code, select, alpha, accumulate_dx);
   }
   if (dw) hipLaunchKernelGGL(small_linear_dw_kernel, dim3(((long)O * I + 255) / 256), dim3(256), 0, S_(stream), dy, x, relu_y, dw, dbias, B, I, O, lddy, row_code, code, x_sub, select, alpha, accumulate_dw);
   return missm_check_launch("small_linear_bwd");
@@ -533,6 +613,20 @@ extern "C" int missm_ema_update(float* teacher, const float* student, long n, fl
   MISSM_CHECK_ARG(n > 0 && decay >= 0.f && decay <= 1.f, "ema_update: bad args");
   hipLaunchKernelGGL(ema_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), teacher, student, n, decay);
   return missm_check_launch("ema_update");
+}
+
+extern "C" int missm_preprocess_image(const void* src, int src_u8, int chw, int H, int W, int C, float* dst, int S, float pre_scale,
+                                      float pre_min, float pre_max, float pre_div, const float* mean3, const float* std3, void* stream) {
+  MISSM_CHECK_ARG(src && dst && H > 0 && W > 0 && (C == 1 || C == 3) && S > 0 && mean3 && std3 && pre_div != 0.f, "preprocess_image: bad args");
+  PrepArgs a;
+  a.src = src; a.dst = dst; a.src_u8 = src_u8; a.chw = chw; a.H = H; a.W = W; a.C = C; a.S = S;
+  // transforms.Resize(S): the shorter edge becomes S, the longer one int(S * long / short); CenterCrop: int(round((n - S) / 2))
+  if (H <= W) { a.new_h = S; a.new_w = (int)((long)S * W / H); } else { a.new_w = S; a.new_h = (int)((long)S * H / W); }
+  a.top = (int)lrintf((a.new_h - S) / 2.0f); a.left = (int)lrintf((a.new_w - S) / 2.0f);
+  a.pre_scale = pre_scale; a.pre_min = pre_min; a.pre_max = pre_max; a.pre_div = pre_div;
+  for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.inv_std[c] = 1.0f / std3[c]; }
+  hipLaunchKernelGGL(preprocess_image_kernel, dim3((S * S + 255) / 256), dim3(256), 0, S_(stream), a);
+  return missm_check_launch("preprocess_image");
 }
 
 extern "C" int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream) {

@@ -81,6 +81,35 @@ def merge_lora_state_dict(sd: Dict[str, torch.Tensor], lora_r: int, lora_alpha: 
     return out
 
 
+def resize_pos_embed(weight: torch.Tensor, grid, extra_tokens: int = 1) -> torch.Tensor:
+    """``resize_pos`` of the reference (image/modeling_image.py:795-839; the audio model maps its square position grid onto the
+    (num_mel_bins, target_length) spectrogram): the class-token rows are kept, the patch rows - a square grid - are resampled to
+    ``grid`` = (rows, columns) with antialiased bicubic interpolation (``F.interpolate(..., mode='bicubic', antialias=True,
+    align_corners=False)``, the reference's own call).  Host-side, once, at load time, like the LoRA merge."""
+    import torch.nn.functional as F
+    gh, gw = int(grid[0]), int(grid[1])
+    if gh * gw + extra_tokens == weight.shape[0]:
+        return weight
+    tok, img = weight[:extra_tokens], weight[extra_tokens:]
+    old = int(math.sqrt(img.shape[0]))
+    if old * old != img.shape[0]:
+        raise ValueError(f"position embedding of {img.shape[0]} patch rows is not a square grid")
+    img = img.float().reshape(1, old, old, -1).permute(0, 3, 1, 2)
+    img = F.interpolate(img, size=(gh, gw), mode="bicubic", antialias=True, align_corners=False)
+    img = img.permute(0, 2, 3, 1).reshape(gh * gw, -1)
+    return torch.cat([tok.float(), img], dim=0).to(weight.dtype)
+
+
+def _vision_config_from_json(raw: dict) -> TowerConfig:
+    fields = TowerConfig.__dataclass_fields__
+    kw = {k: v for k, v in raw.items() if k in fields and k != "kind"}
+    if raw.get("num_mel_bins", 0) and raw.get("target_length", 0):      # audio (image/modeling_image.py:797-798): spectrogram image
+        kw["image_size"] = (int(raw["num_mel_bins"]), int(raw["target_length"]))
+    elif isinstance(kw.get("image_size"), list):
+        kw["image_size"] = tuple(kw["image_size"])
+    return TowerConfig(kind="vision", **kw)
+
+
 class LanguageBindModel(nn.Module):
     """One modality's CLIP pair (reference ``LanguageBind<Modality>``, image/modeling_image.py:734-768): vision tower,
     text tower, the two bias-free projections and ``logit_scale``."""
@@ -134,7 +163,7 @@ class LanguageBindModel(nn.Module):
                                     "LanguageBind(configs=...) or allow_synthetic=True for seeded random towers")
         raw = json.load(open(os.path.join(root, "config.json")))
         fields = TowerConfig.__dataclass_fields__
-        vc = TowerConfig(kind="vision", **{k: v for k, v in raw.get("vision_config", {}).items() if k in fields and k != "kind"})
+        vc = _vision_config_from_json(raw.get("vision_config", {}))
         tc = TowerConfig(kind="text", **{k: v for k, v in raw.get("text_config", {}).items() if k in fields and k != "kind"})
         kw.pop("text_config", None)
         kw.pop("projection_dim", None)
@@ -147,6 +176,9 @@ class LanguageBindModel(nn.Module):
             vraw = raw.get("vision_config", {})
             sd = merge_lora_state_dict(sd, int(vraw.get("lora_r", 2)), float(vraw.get("lora_alpha", 16)))
         sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}     # non-persistent buffers in newer layouts
+        pk = "vision_model.embeddings.position_embedding.weight"
+        if pk in sd and sd[pk].shape[0] != vc.seq_len:                         # a checkpoint trained on another patch grid
+            sd[pk] = resize_pos_embed(sd[pk], vc.grid)
         res = model.load_state_dict(sd, strict=False)
         has_text = hasattr(model, "text_model")
         bad = [k for k in res.unexpected_keys if has_text or not k.startswith(("text_model.", "text_projection."))]
@@ -179,7 +211,20 @@ class _OutOfScope:
     from_pretrained = __call__
 
 
+def _gpu_transform(kind):
+    def make(config=None, **kw):
+        from .. import processing
+        if kind == "depth":
+            vc = (config or {}).get("vision_config", {}) if isinstance(config, dict) else {}
+            return processing.DepthTransform(max_depth=float(vc.get("max_depth", 10)), **kw)
+        return processing.ImageTransform(**kw)
+    return make
+
+
+# image / thermal / depth: GPU-side transforms (processing.py); video decoding and the audio filter bank are host libraries
+# that are not in this image - those entries raise
 transform_dict = {m: _OutOfScope(f"{m} processor") for m in model_dict}
+transform_dict.update({"image": _gpu_transform("image"), "thermal": _gpu_transform("thermal"), "depth": _gpu_transform("depth")})
 LanguageBindImageTokenizer = _OutOfScope("LanguageBindImageTokenizer")
 
 
@@ -308,4 +353,6 @@ class LanguageBind(nn.Module):
 
 
 def to_device(x, device):
-    return {k: v.to(device) for k, v in x.items()}
+    """reference languagebind/__init__.py:87-89; host tensors travel through pinned memory with an asynchronous copy"""
+    from ..processing import to_device_async
+    return to_device_async(x, device)

@@ -399,6 +399,22 @@ def ema_update(teacher, student, decay):
     _lib.call("missm_ema_update", teacher.data_ptr(), student.data_ptr(), teacher.numel(), float(decay), _s())
 
 
+def preprocess_image(src, dst, *, chw: bool, pre_scale: float, pre_min: float, pre_max: float, pre_div: float, mean, std):
+    """one decoded image (device uint8 / fp32, [C,H,W] or [H,W,C], C = 1 or 3) -> dst fp32 [3, S, S]: resize of the shorter edge to S
+    (antialiased bicubic), centre crop, normalisation - see include/missm_hip.h"""
+    import ctypes as C
+    _req(src, "preprocess_image src"); _req(dst, "preprocess_image dst")
+    if src.dtype not in (torch.uint8, torch.float32) or not src.is_contiguous() or src.dim() != 3:
+        raise _lib.MissmError("preprocess_image: src must be a contiguous uint8 / float32 image [C,H,W] or [H,W,C]")
+    Cc, H, W = (src.shape if chw else (src.shape[2], src.shape[0], src.shape[1]))
+    if dst.dtype != torch.float32 or not dst.is_contiguous() or dst.dim() != 3 or dst.shape[0] != 3 or dst.shape[1] != dst.shape[2]:
+        raise _lib.MissmError("preprocess_image: dst must be a contiguous fp32 [3, S, S]")
+    m3, s3 = (C.c_float * 3)(*[float(v) for v in mean]), (C.c_float * 3)(*[float(v) for v in std])
+    _lib.call("missm_preprocess_image", src.data_ptr(), int(src.dtype == torch.uint8), int(chw), int(H), int(W), int(Cc), dst.data_ptr(),
+              int(dst.shape[1]), float(pre_scale), float(pre_min), float(pre_max), float(pre_div), m3, s3, _s())
+    return dst
+
+
 def dropout_fwd(x, y, mask, p, seed):
     _lib.call("missm_dropout_fwd", x.data_ptr(), y.data_ptr(), mask.data_ptr(), x.numel(), float(p), int(seed), _s())
     return y

@@ -43,7 +43,7 @@ class TowerConfig:
     hidden_act: str = "quick_gelu"
     # vision (configuration_image.py:181-232)
     num_channels: int = 3
-    image_size: int = 224
+    image_size: object = 224             # int, or (height, width): the audio tower's spectrogram image (num_mel_bins, target_length)
     patch_size: int = 16
     add_time_attn: bool = False
     num_frames: int = 1
@@ -54,8 +54,19 @@ class TowerConfig:
     max_position_embeddings: int = 77
 
     @property
+    def image_hw(self):
+        hw = self.image_size
+        return (int(hw), int(hw)) if isinstance(hw, int) else (int(hw[0]), int(hw[1]))
+
+    @property
+    def grid(self):
+        """patch grid (rows, columns) - reference resize_pos, image/modeling_image.py:804"""
+        h, w = self.image_hw
+        return h // self.patch_size, w // self.patch_size
+
+    @property
     def seq_len(self) -> int:
-        return (self.image_size // self.patch_size) ** 2 + 1 if self.kind == "vision" else self.max_position_embeddings
+        return self.grid[0] * self.grid[1] + 1 if self.kind == "vision" else self.max_position_embeddings
 
 
 def _r64(n: int) -> int:
@@ -72,8 +83,11 @@ class ClipTower(nn.Module):
             raise NotImplementedError("temporal_mlp (image-family add_time_attn branch) is not on the HIP path yet")
         if c.hidden_size % c.num_attention_heads or (c.hidden_size // c.num_attention_heads) % 8:
             raise ValueError("head_dim must be a multiple of 8")
-        if c.kind == "vision" and (c.patch_size % 4 or c.image_size % c.patch_size):
+        if c.kind == "vision" and (c.patch_size % 4 or c.image_hw[0] % c.patch_size or c.image_hw[1] % c.patch_size):
             raise ValueError("patch_size must be a multiple of 4 and divide image_size")
+        if c.kind == "vision" and c.seq_len > 256 and c.hidden_size // c.num_attention_heads == 64:
+            raise NotImplementedError(f"{c.seq_len} tokens per frame: the attention kernels keep a head's whole K and V in LDS and cover "
+                                      "up to 256 tokens (the released audio checkpoint's 8 x 74 spectrogram grid needs a key-tiled variant)")
         if c.kind == "vision" and c.force_patch_dropout:
             raise NotImplementedError("force_patch_dropout > 0 (random token dropping in training, image/modeling_image.py:30-63) is not "
                                       "implemented; the default configuration uses 0")
@@ -427,6 +441,12 @@ def forward_lanes(towers, inputs, save: bool):
     ss = [SimpleNamespace(layers=[], save=save) for _ in G]
     f32 = dict(device=dev, dtype=torch.float32)
     E = lambda *shape, **kw: [torch.empty(*shape, **kw) for _ in G]      # noqa: E731  one buffer per lane
+
+    def EA(n0, *rest, **kw):
+        """one allocation, one slice per lane (lanes that share a launch over their leading dimension)"""
+        whole = torch.empty(n0 * len(towers), *rest, **kw)
+        return whole, [whole[g * n0:(g + 1) * n0] for g in G]
+
     if c.kind == "vision":
         pxs = []
         for g in G:
@@ -444,7 +464,7 @@ def forward_lanes(towers, inputs, save: bool):
             px = px.to(device=dev, dtype=torch.float32)
             if px.stride(-1) != 1 or px.stride(-2) != px.shape[-1]:
                 px = px.contiguous()
-            if px.shape[-1] != c.image_size or px.shape[-2] != c.image_size or px.shape[1] != c.num_channels:
+            if px.shape[-1] != c.image_hw[1] or px.shape[-2] != c.image_hw[0] or px.shape[1] != c.num_channels:
                 raise ValueError(f"pixel_values spatial/channel shape {tuple(px.shape)} does not match the tower config")
             if c.add_time_attn and Tf != c.num_frames:
                 raise ValueError(f"time attention is configured for {c.num_frames} frames, got {Tf}")
@@ -508,12 +528,17 @@ def forward_lanes(towers, inputs, save: bool):
         m1, r1 = E(rows, **f32), E(rows, **f32)
         for g in G:
             ops.layernorm_fwd(h[g], L[g].ln1_w, L[g].ln1_b, x1[g], m1[g], r1[g], rows, d, c.layer_norm_eps)
-        qkv = E(rows, 3 * d, device=dev, dtype=T)
+        # (the lanes' QKV / context / log-sum-exp buffers are slices of ONE allocation: the sequences of all lanes are one
+        #  attention launch - four 384-(frame, head) launches fill 512 workgroup slots to 75 % each, one 1536-unit launch runs
+        #  three full rounds in which one workgroup's K / V fetch overlaps another's arithmetic)
+        qkv_all, qkv = EA(rows, 3 * d, device=dev, dtype=T)
         ops.gemm_grouped(x1, W(f"{pfx}.qkv", 0), qkv, bias=[l.qkv_b for l in L])
-        ctx = E(rows, d, device=dev, dtype=T)
-        lse = E(N * H * S, **f32)
-        for g in G:
-            ops.attention_fwd(qkv[g], ctx[g], lse[g], N, S, H, hd, causal=causal, key_mask=key_mask[g])
+        ctx_all, ctx = EA(rows, d, device=dev, dtype=T)
+        lse_all, lse = EA(N * H * S, **f32)
+        if len(towers) > 1:
+            ops.attention_fwd(qkv_all, ctx_all, lse_all, N * len(towers), S, H, hd, causal=causal)
+        else:
+            ops.attention_fwd(qkv[0], ctx[0], lse[0], N, S, H, hd, causal=causal, key_mask=key_mask[0])
         h2 = E(rows, d, **f32)
         ops.gemm_grouped(ctx, W(f"{pfx}.out", 0), h2, bias=[l.out_b for l in L], resid=h)
         x2 = E(rows, d, device=dev, dtype=T)
@@ -529,6 +554,7 @@ def forward_lanes(towers, inputs, save: bool):
             for g in G:
                 recs[g].a = (h[g], x1[g], m1[g], r1[g], qkv[g], ctx[g], lse[g])
                 recs[g].m = (h2[g], x2[g], m2[g], r2[g], u[g], a[g])
+                recs[g].a_all = (qkv_all, ctx_all, lse_all) if g == 0 else None
                 ss[g].layers.append(recs[g])
         h = h3
     out = []
@@ -616,11 +642,17 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
             ops.layernorm_bwd(dx2[g], h2[g], m2[g], r2[g], L[g].ln2_w, dh[g], L[g].g_ln2_w, L[g].g_ln2_b, rows, d, accumulate=True, dx_cast=dh_T[g])
         # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
         hin, x1, m1, r1, qkv, ctx, lse = (list(v) for v in zip(*[r.a for r in recs]))
-        dctx = E(rows, d, device=dev, dtype=T)
+        dctx_all = torch.empty(rows * len(towers), d, device=dev, dtype=T)
+        dctx = [dctx_all[g * rows:(g + 1) * rows] for g in G]
         _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], rows, dx_outs=dctx)
-        dqkv = E(rows, 3 * d, device=dev, dtype=T)
-        for g in G:
-            ops.attention_bwd(qkv[g], ctx[g], dctx[g], lse[g], dqkv[g], N, S, H, hd, causal=states[g].causal, key_mask=states[g].key_mask)
+        if len(towers) > 1:      # one launch over every lane's sequences (forward_lanes made the saved buffers slices of one allocation)
+            qkv_all, ctx_all, lse_all = recs[0].a_all
+            dqkv_all = torch.empty(rows * len(towers), 3 * d, device=dev, dtype=T)
+            dqkv = [dqkv_all[g * rows:(g + 1) * rows] for g in G]
+            ops.attention_bwd(qkv_all, ctx_all, dctx_all, lse_all, dqkv_all, N * len(towers), S, H, hd, causal=states[0].causal)
+        else:
+            dqkv = E(rows, 3 * d, device=dev, dtype=T)
+            ops.attention_bwd(qkv[0], ctx[0], dctx[0], lse[0], dqkv[0], N, S, H, hd, causal=states[0].causal, key_mask=states[0].key_mask)
         dx1 = E(rows, d, device=dev, dtype=T)
         _linear_bwd_lanes(towers, dqkv, x1, W(f"{pfx}.qkv", 1), [l.g_qkv_w for l in L], [l.g_qkv_b for l in L], rows, dx_outs=dx1)
         for g in G:

@@ -247,6 +247,40 @@ def bundle_fixture(name, seed):
     print(f"{name}: ref-vs-oracle {err:.2e}")
 
 
+def resize_pos_fixture(name, seed):
+    """``resize_pos`` (image/modeling_image.py:795-839) run from the reference's source on a stand-in embeddings module: a 4 x 4
+    position grid (+ class token) mapped onto the audio model's (num_mel_bins, target_length) patch grid."""
+    import ast
+    import math
+    import torch.nn as nn
+    import torch.nn.functional as F
+    src = open(ref_shims.REF_ROOT + "/languagebind/image/modeling_image.py").read()
+    tree = ast.parse(src)
+    cls = next(n for n in tree.body if isinstance(n, ast.ClassDef) and n.name == "LanguageBindImage")
+    fn = next(n for n in cls.body if isinstance(n, ast.FunctionDef) and n.name == "resize_pos")
+    ns = {"torch": torch, "nn": nn, "F": F, "math": math}
+    exec(compile(ast.Module(body=[fn], type_ignores=[]), "modeling_image.py", "exec"), ns)
+    g = _gen(seed)
+    d, ps = 24, 16
+
+    class _Emb(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.image_size, self.patch_size, self.embed_dim = 64, ps, d
+            self.config = types.SimpleNamespace(image_size=64)
+            self.position_embedding = nn.Embedding(17, d)
+            self.position_embedding.weight.data = torch.randn(17, d, generator=g)
+
+    m = _Emb()
+    old = m.position_embedding.weight.detach().clone()
+    vc = types.SimpleNamespace(num_mel_bins=48, target_length=112)
+    ns["resize_pos"](None, m, vc)
+    new = m.position_embedding.weight.detach().clone()
+    fix = {"old": old, "grid": (48 // ps, 112 // ps), "new": new, "num_mel_bins": 48, "target_length": 112, "patch_size": ps}
+    torch.save(fix, os.path.join(OUT, name + ".pt"))
+    print(f"{name}: ref-vs-oracle {float((O.resize_pos_embed(old, fix['grid']) - new).abs().max()):.2e}  shape {tuple(new.shape)}")
+
+
 def losses_fixture(name, seed):
     """The distillation losses of the student training modes, from the reference's own source: class ``KL_loss``
     (train_ddp.py:70-79) is compiled from the file (the module itself needs tensorboard / datasets and is not importable), and
@@ -360,6 +394,7 @@ def main():
         seed=27, fusion_type="self_distill")
     run(bundle_fixture, "bundle", seed=12)
     run(losses_fixture, "distill_losses", seed=31)
+    run(resize_pos_fixture, "resize_pos", seed=33)
     run(missing_fixture, "missing_index")
     # BASELINE.json configs[0]: image tower ViT-B/16 forward, B=4, 224x224 (weights by recipe, outputs stored)
     run(vision_fixture, "vitb16_config1", "image", O.VisionCfg(), batch=4, seed_w=0, seed_x=1, store_params=False, compact=True)

@@ -48,7 +48,7 @@ class VisionCfg:
     num_hidden_layers: int = 12
     num_attention_heads: int = 12
     num_channels: int = 3
-    image_size: int = 224
+    image_size: object = 224  # int or (height, width): resize_pos gives the audio model a (num_mel_bins, target_length) image
     patch_size: int = 16
     layer_norm_eps: float = 1e-5
     hidden_act: str = "quick_gelu"
@@ -60,7 +60,9 @@ class VisionCfg:
 
     @property
     def num_patches(self) -> int:
-        return (self.image_size // self.patch_size) ** 2
+        hw = self.image_size
+        h, w = (hw, hw) if isinstance(hw, int) else hw
+        return (h // self.patch_size) * (w // self.patch_size)
 
     @property
     def seq_len(self) -> int:
@@ -418,6 +420,45 @@ def fusion_self_distillation(emb: Dict[str, Tensor], missing_index: Tensor, fp: 
 def cross_entropy(logits: Tensor, labels: Tensor) -> Tensor:
     """``nn.CrossEntropyLoss()`` train_ddp.py:88,250 (mean over batch)."""
     return F.cross_entropy(logits, labels)
+
+
+def resize_pos_embed(weight: Tensor, grid: Sequence[int], extra_tokens: int = 1) -> Tensor:
+    """``resize_pos`` image/modeling_image.py:795-839: class-token rows kept, the square patch grid resampled to ``grid`` with
+    the reference's own third-party call ``F.interpolate(mode='bicubic', antialias=True, align_corners=False)``."""
+    if grid[0] * grid[1] + extra_tokens == weight.shape[0]:
+        return weight
+    tok, img = weight[:extra_tokens], weight[extra_tokens:]
+    old = int(math.sqrt(len(img)))
+    img = img.reshape(1, old, old, -1).permute(0, 3, 1, 2)
+    img = F.interpolate(img, size=list(grid), mode="bicubic", antialias=True, align_corners=False)
+    img = img.permute(0, 2, 3, 1).reshape(1, grid[0] * grid[1], -1)[0]
+    return torch.cat([tok, img], dim=0)
+
+
+OPENAI_DATASET_MEAN = (0.48145466, 0.4578275, 0.40821073)
+OPENAI_DATASET_STD = (0.26862954, 0.26130258, 0.27577711)
+
+
+def image_transform(img_chw: Tensor, size: int = 224) -> Tensor:
+    """``get_image_transform`` image/processing_image.py:18-28 after ToTensor (img_chw float [C,H,W] in [0,1]):
+    torchvision ``Resize(size, BICUBIC)`` on a tensor = ``F.interpolate(mode='bicubic', antialias=True, align_corners=False)`` of the
+    shorter edge to ``size`` (longer edge int(size * long / short)); ``CenterCrop`` (offsets int(round((n - size) / 2)));
+    ``Normalize``.  torchvision is absent from this image and unpinned upstream: parity unpinned (restated from its source)."""
+    c, h, w = img_chw.shape
+    nh, nw = (size, int(size * w / h)) if h <= w else (int(size * h / w), size)
+    r = F.interpolate(img_chw[None], size=[nh, nw], mode="bicubic", antialias=True, align_corners=False)[0]
+    top, left = int(round((nh - size) / 2.0)), int(round((nw - size) / 2.0))
+    r = r[:, top:top + size, left:left + size]
+    mean, std = torch.tensor(OPENAI_DATASET_MEAN)[:, None, None], torch.tensor(OPENAI_DATASET_STD)[:, None, None]
+    return (r - mean) / std
+
+
+def depth_transform(depth_hw: Tensor, max_depth: float = 10.0, size: int = 224) -> Tensor:
+    """``get_depth_transform`` depth/processing_depth.py:21-55: DepthNorm (/1000, clip to [0.01, max_depth], / max_depth, repeated to
+    3 channels) followed by the image pipeline."""
+    d = (depth_hw / 1000.0).clip(min=0.01)
+    d = d.clip(max=max_depth) / max_depth if max_depth != 0 else d / d.max()
+    return image_transform(d[None].repeat(3, 1, 1), size)
 
 
 def kl_loss(g_s: Tensor, g_t: Tensor, temperature: float = 0.15) -> Tensor:

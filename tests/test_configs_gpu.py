@@ -156,7 +156,7 @@ def test_config1_b32_properties(pkg):
     with torch.no_grad():
         sub = {m: {k: v[:4] for k, v in d.items()} for m, d in gdata.items()}
         l4 = model(sub, missing[:4].cuda())
-    assert rel(l4, logits[:4]) < 2e-3                               # samples do not see each other
+    assert rel(l4, logits[:4]) < 5e-3                               # samples do not see each other (bf16: B = 4 and B = 32 take different GEMM tiles)
     names = ["encoder.modality_encoder.language.encoder.layers.0.self_attn.q_proj.weight",
              "encoder.modality_encoder.language.encoder.layers.11.mlp.fc2.weight",
              "encoder.modality_encoder.image.encoder.layers.3.mlp.fc1.weight"]
@@ -367,3 +367,25 @@ def test_lockstep_tower_groups_equal_separate_towers(pkg):
     with torch.no_grad():
         ologits, _ = O.finetune_forward({m: {"pixel_values": data[m]["pixel_values"][idx]} for m in mods}, missing[idx], tp, ocfg, proj, scales, fp, mods)
     assert rel(runs[True][0][:2], ologits) < 5e-2
+
+
+def test_non_square_spectrogram_tower_vs_oracle(pkg):
+    """the audio model's (num_mel_bins, target_length) image (reference resize_pos, image/modeling_image.py:795-839): a tower over a
+    2 x 4 patch grid against the CPU oracle, forward and gradients, fp32 instantiation"""
+    cfg = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=(32, 64), patch_size=16)
+    ocfg = O.VisionCfg(**cfg)
+    params = O.init_tower_params(ocfg, 4)
+    assert params["embeddings.position_embedding.weight"].shape[0] == 9
+    tower = make_tower(pkg, cfg, "vision", params, torch.float32)
+    x = torch.randn(3, 3, 32, 64, generator=torch.Generator().manual_seed(2))
+    last, pooled = tower(x.cuda())
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    olast, opooled = O.vision_tower(x, p, ocfg)
+    assert rel(pooled, opooled) < TOL32 and rel(last, olast) < TOL32
+    cot = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(3))
+    (pooled * cot.cuda()).sum().backward()
+    (opooled * cot).sum().backward()
+    for k in ("embeddings.position_embedding.weight", "embeddings.patch_embedding.weight", "encoder.layers.1.mlp.fc1.weight"):
+        assert rel(tower.get_parameter(k).grad, p[k].grad) < 2e-3, k
+    with pytest.raises(ValueError):
+        tower(torch.randn(1, 3, 64, 32).cuda())               # height / width swapped

@@ -557,3 +557,25 @@ def test_distillation_losses_vs_reference_fixture():
     pt = fix["ema"]["tea"].cuda().clone()
     OPS.ema_update(pt, fix["ema"]["stu"].cuda(), 0.999)
     assert float((pt.cpu() - fix["ema"]["out"]).abs().max()) < 1e-6
+
+
+@pytest.mark.parametrize("hw", [(300, 400), (480, 360), (224, 224), (150, 500)])
+def test_gpu_image_and_depth_transforms_vs_oracle(hw):
+    """processing.ImageTransform / DepthTransform (uint8 HWC / float32 HW in, pixel_values out: resize of the shorter edge with
+    antialiased bicubic, centre crop, normalisation in one launch) against the oracle's torch restatement of the reference transforms
+    (image/processing_image.py:18-28, depth/processing_depth.py:21-55); up- and down-sampling, both orientations."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import missm_oracle as O
+    from missm_benchmark_amd.processing import DepthTransform, ImageTransform
+    g = torch.Generator().manual_seed(hw[0] * 1000 + hw[1])
+    img = torch.randint(0, 256, (hw[0], hw[1], 3), generator=g, dtype=torch.uint8)
+    got = ImageTransform()(img.numpy())
+    want = O.image_transform(img.permute(2, 0, 1).float() / 255.0)
+    assert got.shape == (3, 224, 224) and float((got.cpu() - want).abs().max()) < 2e-4
+    batch = ImageTransform()([img.numpy(), img.numpy()[::-1].copy()])
+    assert batch.shape == (2, 3, 224, 224) and torch.equal(batch[0], got)
+    depth = torch.rand(hw[0], hw[1], generator=g) * 12000.0           # millimetres, some beyond max_depth = 10 m
+    gd = DepthTransform(max_depth=10.0)(depth.numpy())
+    wd = O.depth_transform(depth, 10.0)
+    assert float((gd.cpu() - wd).abs().max()) < 2e-4

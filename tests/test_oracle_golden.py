@@ -232,3 +232,18 @@ def test_distillation_losses_vs_reference():
     assert all((t.grad - g).abs().max() < TOL for t, g in zip(stu, sd["stu_grads"])) and (logits.grad - sd["logits_grad"]).abs().max() < TOL
     assert sd["tea_grad"] is None or float(sd["tea_grad"].abs().max()) == 0.0       # the teacher side is detached
     assert (O.ema_update(fix["ema"]["tea"], fix["ema"]["stu"]) - fix["ema"]["out"]).abs().max() < 1e-7
+
+
+def test_resize_pos_vs_reference():
+    """resize_pos (image/modeling_image.py:795-839, run from the reference source when the fixture was made): oracle and product"""
+    import sys
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from missm_benchmark_amd.languagebind import _vision_config_from_json, resize_pos_embed
+    fix = load_golden("resize_pos")
+    assert (O.resize_pos_embed(fix["old"], fix["grid"]) - fix["new"]).abs().max() < TOL
+    assert (resize_pos_embed(fix["old"], fix["grid"]) - fix["new"]).abs().max() < TOL
+    assert resize_pos_embed(fix["new"], fix["grid"]) is fix["new"]            # already the right grid: untouched
+    vc = _vision_config_from_json({"hidden_size": 64, "patch_size": fix["patch_size"], "num_mel_bins": fix["num_mel_bins"],
+                                   "target_length": fix["target_length"], "image_size": 224})
+    assert vc.image_hw == (fix["num_mel_bins"], fix["target_length"]) and vc.grid == tuple(fix["grid"]) and vc.seq_len == fix["new"].shape[0]
