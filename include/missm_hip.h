@@ -161,9 +161,10 @@ int missm_small_linear_bwd(const float* dy, int lddy, const float* x, const floa
 /* dst[b, 0:W] += src[b, 0:W] with row strides lddst / ldsrc (gradient slices of a concatenated feature row meeting again). */
 int missm_add_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, void* stream);
 /* dst[b, 0:W] = row_code[b] == code ? 0 : src[b, 0:W]: one modality's block of the concatenated feature row with its missing
- * rows zeroed (the distillation heads, src/model/baseline.py:370-376); also its own backward. */
+ * rows zeroed (the distillation heads, src/model/baseline.py:370-376); also its own backward.  keep_matching != 0 inverts the
+ * selection (only the rows that carry the code are copied: the unified graph head's "fill the missing modality", :311). */
 int missm_masked_copy_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, const long* row_code, long code,
-                            void* stream);
+                            int keep_matching, void* stream);
 /* Channel-attention gate of the intra-modality attention head (src/model/baseline.py:198-201):
  * y[b,f] (= or +=) row b missing ? 0 : d[b,f] * sigmoid(pre[b,f]); d has row stride ldd.  Backward: dd (stride lddd, = or +=)
  * and dpre, both zero for missing rows. */
@@ -192,6 +193,18 @@ int missm_ema_update(float* teacher, const float* student, long n, float decay, 
  * images 1/255, -inf.., 1 ; depth 1/1000, 0.01, max_depth, max_depth.  dst: fp32 [3, S, S].  mean3 / std3: HOST arrays. */
 int missm_preprocess_image(const void* src, int src_u8, int chw, int H, int W, int C, float* dst, int S, float pre_scale, float pre_min,
                            float pre_max, float pre_div, const float* mean3, const float* std3, void* stream);
+/* SuperGAT attention over per-sample modality graphs (fusion_gcn of the graph heads, src/model/baseline.py:11-24,240-331:
+ * torch_geometric SuperGATConv, 'MX' attention, self loops, negative_slope 0.2).  xp = lin(x) [B, M, H, C], M <= 8 nodes; an edge
+ * j -> i exists iff i == j or node_ok[b,i] && node_ok[b,j].  out [B, M, H, C] (before the head concat / mean and the bias), alpha
+ * [B, H, M, M] saved for the backward.  PARITY UNPINNED: torch_geometric is absent and unpinned upstream; restated from the paper. */
+int missm_sgat_fwd(const float* xp, const float* att_l, const float* att_r, const unsigned char* node_ok, const float* bias, float* out,
+                   float* out_gelu, float* alpha, int B, int M, int H, int C, void* stream);
+/* dx = dy * gelu'(pre) (exact erf form): the nn.GELU between the two SuperGAT layers (src/model/baseline.py:16,21); missm_sgat_fwd
+ * writes gelu(out) to out_gelu when that pointer is given.  bias [H*C] (optional) is added to out. */
+int missm_gelu_bwd(const float* dy, const float* pre, float* dx, long n, void* stream);
+/* backward: dxp [B, M, H, C]; per-sample partial sums of the attention-vector gradients [B, H, C] (summed over the batch afterwards). */
+int missm_sgat_bwd(const float* xp, const float* att_l, const float* att_r, const unsigned char* node_ok, const float* alpha, const float* dout,
+                   float* dxp, float* datt_l_part, float* datt_r_part, int B, int M, int H, int C, void* stream);
 /* inverted dropout with a counter-based generator: y = x * mask / (1-p); mask saved as bytes (src/model/baseline.py:34). */
 int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream);
 int missm_dropout_bwd(const float* dy, const unsigned char* mask, float* dx, long n, float p, void* stream);

@@ -34,7 +34,7 @@ SIGNATURES = {
     "missm_argmax_rows": [P, P, I, I, P],
     "missm_small_linear_fwd": [P, P, P, P, I, I, I, I, I, P, L, P, I, F, I, P],
     "missm_add_block": [P, I, P, I, I, I, P],
-    "missm_masked_copy_block": [P, I, P, I, I, I, P, L, P],
+    "missm_masked_copy_block": [P, I, P, I, I, I, P, L, I, P],
     "missm_small_linear_bwd": [P, I, P, P, P, P, P, P, I, I, I, P, L, P, I, F, I, I, P],
     "missm_gate_fwd": [P, I, P, P, I, I, P, L, I, P],
     "missm_gate_bwd": [P, P, I, P, P, I, P, I, I, P, L, I, P],
@@ -45,6 +45,9 @@ SIGNATURES = {
     "missm_mse_loss": [P, P, P, P, L, P],
     "missm_ema_update": [P, P, L, F, P],
     "missm_preprocess_image": [P, I, I, I, I, I, P, I, F, F, F, F, P, P, P],
+    "missm_sgat_fwd": [P, P, P, P, P, P, P, P, I, I, I, I, P],
+    "missm_gelu_bwd": [P, P, P, L, P],
+    "missm_sgat_bwd": [P, P, P, P, P, P, P, P, P, I, I, I, I, P],
     "missm_dropout_fwd": [P, P, P, L, F, U64, P],
     "missm_dropout_bwd": [P, P, P, L, F, P],
     "missm_adam_step": [P, P, P, P, L, I, F, F, F, F, F, F, P],
@@ -53,7 +56,7 @@ SIGNATURES = {
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
-ABI_VERSION = 6     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 7     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

@@ -114,8 +114,16 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     const float* xr = a.x + irow * a.cols;
     const Tin* dyr = static_cast<const Tin*>(a.dy) + (size_t)(row / a.dy_div) * a.cols;
     const float mean = a.mean[row], rstd = a.rstd[row];
-    f32x4 xh[CH], g[CH];
+    f32x4 xh[CH], g[CH], prev[CH];
     float s1 = 0.f, s2 = 0.f;
+    float* dxr = a.dx + irow * a.cols;
+    // the running residual gradient this row's result is added to is requested together with x and dy (it used to be loaded
+    // after the two row reductions: a second memory round trip per row with nothing else in flight in the wave)
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      prev[c] = (a.accumulate && col < a.cols) ? load4(dxr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int col = (c * 64 + lane) * 4;
@@ -138,7 +146,6 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     }
     s1 = wave_sum(s1) * inv;
     s2 = wave_sum(s2) * inv;
-    float* dxr = a.dx + irow * a.cols;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int col = (c * 64 + lane) * 4;
@@ -146,7 +153,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[c][j] - s1 - xh[c][j] * s2);
-        if (a.accumulate) { const f32x4 p = load4(dxr + col); o += p; }
+        o += prev[c];
         store4(dxr + col, o);
         if (a.dx_cast) store4(static_cast<Tin*>(a.dx_cast) + irow * a.cols + col, o);
       }

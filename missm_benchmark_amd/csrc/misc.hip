@@ -397,6 +397,111 @@ __global__ __launch_bounds__(256) void preprocess_image_kernel(PrepArgs a) {
   }
 }
 
+
+// ---- SuperGAT attention over the per-sample modality graphs of the graph-fusion heads (reference src/model/baseline.py:11-24,
+// 240-331: torch_geometric.nn.SuperGATConv, attention_type 'MX', self loops added, negative_slope 0.2; the self-supervised
+// link-prediction loss it also computes in training never reaches the output and is not used by the reference).
+// torch_geometric is absent and unpinned upstream: restated from the published algorithm (Kim & Oh, ICLR 2021) - PARITY UNPINNED.
+// One wavefront per (sample, head).  xp = lin(x) [B, M, H, C] (M <= 8 nodes).  Edge j -> i exists iff i == j or both nodes are
+// present (node_ok).  e_ij = leaky_relu((xp_j . att_l + xp_i . att_r) * sigmoid(xp_i . xp_j)); alpha_i. = softmax_j over the edges;
+// out_i = sum_j alpha_ij xp_j.
+constexpr int kMaxNodes = 8;
+struct SgatArgs { const float* xp; const float* att_l; const float* att_r; const unsigned char* node_ok; float* out; float* alpha;
+                  const float* dout; float* dxp; float* datt_l_part; float* datt_r_part; int B, M, H, C;
+                  const float* bias; float* out_act; const float* pre; };   // out = conv + bias; out_act = gelu(out) (optional); pre: saved out
+
+__device__ __forceinline__ void sgat_scores(const SgatArgs& a, int b, int h, int lane, float (&sl)[kMaxNodes], float (&sr)[kMaxNodes],
+                                            float (&lg)[kMaxNodes][kMaxNodes]) {
+  const float* x = a.xp + ((size_t)b * a.M * a.H + h) * a.C;     // node j at x + j * H * C
+  const size_t ns = (size_t)a.H * a.C;
+  for (int j = 0; j < a.M; ++j) {
+    float pl = 0.f, pr = 0.f;
+    for (int c = lane; c < a.C; c += 64) { const float v = x[j * ns + c]; pl += v * a.att_l[h * a.C + c]; pr += v * a.att_r[h * a.C + c]; }
+    sl[j] = wave_sum(pl); sr[j] = wave_sum(pr);
+  }
+  for (int i = 0; i < a.M; ++i)
+    for (int j = i; j < a.M; ++j) {
+      float pd = 0.f;
+      for (int c = lane; c < a.C; c += 64) pd += x[i * ns + c] * x[j * ns + c];
+      lg[i][j] = lg[j][i] = wave_sum(pd);
+    }
+}
+
+__global__ __launch_bounds__(64) void sgat_fwd_kernel(SgatArgs a) {
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, lane = threadIdx.x;
+  float sl[kMaxNodes], sr[kMaxNodes], lg[kMaxNodes][kMaxNodes];
+  sgat_scores(a, b, h, lane, sl, sr, lg);
+  const float* x = a.xp + ((size_t)b * a.M * a.H + h) * a.C;
+  const size_t ns = (size_t)a.H * a.C;
+  for (int i = 0; i < a.M; ++i) {
+    float e[kMaxNodes], mx = -__builtin_huge_valf();
+    for (int j = 0; j < a.M; ++j) {
+      const bool edge = i == j || (a.node_ok[b * a.M + i] && a.node_ok[b * a.M + j]);
+      float v = (sl[j] + sr[i]) / (1.f + expf(-lg[i][j]));
+      v = v > 0.f ? v : 0.2f * v;
+      e[j] = edge ? v : -__builtin_huge_valf();
+      mx = fmaxf(mx, e[j]);
+    }
+    float z = 0.f;
+    for (int j = 0; j < a.M; ++j) { e[j] = expf(e[j] - mx); z += e[j]; }
+    for (int j = 0; j < a.M; ++j) {
+      e[j] /= z;
+      if (lane == 0) a.alpha[(((size_t)b * a.H + h) * a.M + i) * a.M + j] = e[j];
+    }
+    for (int c = lane; c < a.C; c += 64) {
+      float o = a.bias ? a.bias[h * a.C + c] : 0.f;
+      for (int j = 0; j < a.M; ++j) o += e[j] * x[j * ns + c];
+      const size_t oi = ((size_t)(b * a.M + i) * a.H + h) * a.C + c;
+      a.out[oi] = o;
+      if (a.out_act) a.out_act[oi] = gelu_erf(o);
+    }
+  }
+}
+
+// backward of the above from d out [B, M, H, C]: d xp, and per-sample partial sums of d att_l / d att_r [B, H, C] (summed over the
+// batch by a column-sum launch afterwards: a fixed order, bit-reproducible)
+__global__ __launch_bounds__(64) void sgat_bwd_kernel(SgatArgs a) {
+  const int b = blockIdx.x / a.H, h = blockIdx.x % a.H, lane = threadIdx.x;
+  float sl[kMaxNodes], sr[kMaxNodes], lg[kMaxNodes][kMaxNodes];
+  sgat_scores(a, b, h, lane, sl, sr, lg);
+  const float* x = a.xp + ((size_t)b * a.M * a.H + h) * a.C;
+  const float* go = a.dout + ((size_t)b * a.M * a.H + h) * a.C;          // (already multiplied by gelu'(pre) by the caller kernel below)
+  const float* al = a.alpha + ((size_t)b * a.H + h) * a.M * a.M;
+  const size_t ns = (size_t)a.H * a.C;
+  float dsl[kMaxNodes], dsr[kMaxNodes], dlg[kMaxNodes][kMaxNodes];
+  for (int j = 0; j < a.M; ++j) { dsl[j] = 0.f; dsr[j] = 0.f; }
+  for (int i = 0; i < a.M; ++i) {
+    float da[kMaxNodes], dot = 0.f;
+    for (int j = 0; j < a.M; ++j) {
+      float pd = 0.f;
+      for (int c = lane; c < a.C; c += 64) pd += go[i * ns + c] * x[j * ns + c];
+      da[j] = wave_sum(pd);                              // d alpha_ij
+      dot += al[i * a.M + j] * da[j];
+    }
+    for (int j = 0; j < a.M; ++j) {
+      const float p = al[i * a.M + j];
+      float de = p * (da[j] - dot);                      // softmax backward (p = 0 on non-edges)
+      const float sg = 1.f / (1.f + expf(-lg[i][j])), t = sl[j] + sr[i], pre = t * sg;
+      de *= pre > 0.f ? 1.f : 0.2f;                      // leaky_relu backward
+      dsl[j] += de * sg; dsr[i] += de * sg;
+      dlg[i][j] = de * t * sg * (1.f - sg);
+    }
+  }
+  for (int c = lane; c < a.C; c += 64) {
+    const float wl = a.att_l[h * a.C + c], wr = a.att_r[h * a.C + c];
+    float pl = 0.f, pr = 0.f;
+    for (int n = 0; n < a.M; ++n) {
+      float d = dsl[n] * wl + dsr[n] * wr;
+      for (int i = 0; i < a.M; ++i) d += al[i * a.M + n] * go[i * ns + c];                 // out_i = sum_j alpha_ij xp_j
+      for (int m = 0; m < a.M; ++m) d += (dlg[n][m] + dlg[m][n]) * x[m * ns + c];          // logit_ij = xp_i . xp_j
+      a.dxp[((size_t)(b * a.M + n) * a.H + h) * a.C + c] = d;
+      pl += dsl[n] * x[n * ns + c]; pr += dsr[n] * x[n * ns + c];
+    }
+    a.datt_l_part[((size_t)b * a.H + h) * a.C + c] = pl;
+    a.datt_r_part[((size_t)b * a.H + h) * a.C + c] = pr;
+  }
+}
+
 __device__ __forceinline__ uint32_t hash_u64(unsigned long long x) {  // splitmix64 finaliser
   x += 0x9E3779B97F4A7C15ull;
   x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
@@ -543,17 +648,18 @@ __global__ __launch_bounds__(256) void add_block_kernel(float* __restrict__ dst,
 // dst[b, 0:W] = row b carries the code ? 0 : src[b, 0:W]   (a modality's embedding block of the concatenated feature row with
 // its missing rows zeroed, src/model/baseline.py:370-374; the same kernel maps the gradient back)
 __global__ __launch_bounds__(256) void masked_copy_block_kernel(float* __restrict__ dst, int lddst, const float* __restrict__ src, int ldsrc,
-                                                               int B, int W, const long* __restrict__ row_code, long code) {
+                                                               int B, int W, const long* __restrict__ row_code, long code, int keep_matching) {
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
   if (idx >= (long)B * W) return;
   const int b = idx / W, c = idx % W;
-  dst[(long)b * lddst + c] = (row_code && row_code[b] == code) ? 0.f : src[(long)b * ldsrc + c];
+  const bool hit = row_code && row_code[b] == code;
+  dst[(long)b * lddst + c] = (hit != (keep_matching != 0)) ? 0.f : src[(long)b * ldsrc + c];   // (no codes: keep_matching must be 0)
 }
 
 extern "C" int missm_masked_copy_block(float* dst, int lddst, const float* src, int ldsrc, int B, int W, const long* row_code, long code,
-                                       void* stream) {
-  MISSM_CHECK_ARG(B > 0 && W > 0 && lddst >= W && ldsrc >= W, "masked_copy_block: bad shape");
-  hipLaunchKernelGGL(masked_copy_block_kernel, dim3(((long)B * W + 255) / 256), dim3(256), 0, S_(stream), dst, lddst, src, ldsrc, B, W, row_code, code);
+                                       int keep_matching, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && W > 0 && lddst >= W && ldsrc >= W && (!keep_matching || row_code), "masked_copy_block: bad shape");
+  hipLaunchKernelGGL(masked_copy_block_kernel, dim3(((long)B * W + 255) / 256), dim3(256), 0, S_(stream), dst, lddst, src, ldsrc, B, W, row_code, code, keep_matching);
   return missm_check_launch("masked_copy_block");
 }
 
@@ -627,6 +733,33 @@ extern "C" int missm_preprocess_image(const void* src, int src_u8, int chw, int 
   for (int c = 0; c < 3; ++c) { a.mean[c] = mean3[c]; a.inv_std[c] = 1.0f / std3[c]; }
   hipLaunchKernelGGL(preprocess_image_kernel, dim3((S * S + 255) / 256), dim3(256), 0, S_(stream), a);
   return missm_check_launch("preprocess_image");
+}
+
+// dy_eff = dy * gelu'(pre)   (the GELU between the two SuperGAT layers of fusion_gcn, src/model/baseline.py:16,21)
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ pre, float* __restrict__ dx, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dx[i] = dy[i] * gelu_erf_grad(pre[i]);
+}
+
+extern "C" int missm_gelu_bwd(const float* dy, const float* pre, float* dx, long n, void* stream) {
+  MISSM_CHECK_ARG(n > 0 && dy && pre && dx, "gelu_bwd: bad args");
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n, 2048)), dim3(256), 0, S_(stream), dy, pre, dx, n);
+  return missm_check_launch("gelu_bwd");
+}
+
+extern "C" int missm_sgat_fwd(const float* xp, const float* att_l, const float* att_r, const unsigned char* node_ok, const float* bias,
+                              float* out, float* out_gelu, float* alpha, int B, int M, int H, int C, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && M > 0 && M <= kMaxNodes && H > 0 && C > 0 && xp && att_l && att_r && node_ok && out && alpha, "sgat_fwd: bad args (at most 8 nodes)");
+  SgatArgs a{xp, att_l, att_r, node_ok, out, alpha, nullptr, nullptr, nullptr, nullptr, B, M, H, C, bias, out_gelu, nullptr};
+  hipLaunchKernelGGL(sgat_fwd_kernel, dim3(B * H), dim3(64), 0, S_(stream), a);
+  return missm_check_launch("sgat_fwd");
+}
+
+extern "C" int missm_sgat_bwd(const float* xp, const float* att_l, const float* att_r, const unsigned char* node_ok, const float* alpha,
+                              const float* dout, float* dxp, float* datt_l_part, float* datt_r_part, int B, int M, int H, int C, void* stream) {
+  MISSM_CHECK_ARG(B > 0 && M > 0 && M <= kMaxNodes && H > 0 && C > 0 && xp && alpha && dout && dxp && datt_l_part && datt_r_part, "sgat_bwd: bad args");
+  SgatArgs a{xp, att_l, att_r, node_ok, nullptr, const_cast<float*>(alpha), dout, dxp, datt_l_part, datt_r_part, B, M, H, C, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(sgat_bwd_kernel, dim3(B * H), dim3(64), 0, S_(stream), a);
+  return missm_check_launch("sgat_bwd");
 }
 
 extern "C" int missm_dropout_fwd(const float* x, float* y, unsigned char* mask, long n, float p, unsigned long long seed, void* stream) {

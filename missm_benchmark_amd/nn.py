@@ -603,3 +603,162 @@ class HipMSELoss(nn.Module):
 
     def forward(self, a, b):
         return _MSELossFn.apply(a, b)
+
+
+class _SuperGATFn(torch.autograd.Function):
+    """one SuperGATConv over the batch of per-sample modality graphs (see missm_sgat_fwd): lin -> attention -> (+ bias) [-> GELU]"""
+
+    @staticmethod
+    def forward(ctx, x, w, att_l, att_r, bias, node_ok, heads, gelu):
+        _gpu(x, "SuperGATConv")
+        B, M = node_ok.shape
+        HC = w.shape[0]
+        Cc = HC // heads
+        x = x.contiguous()
+        xp = torch.empty(B * M, HC, device=x.device, dtype=torch.float32)
+        ops.small_linear_fwd(x, w, None, xp)
+        out = torch.empty(B * M, HC, device=x.device, dtype=torch.float32)
+        act = torch.empty_like(out) if gelu else None
+        alpha = torch.empty(B * heads * M * M, device=x.device, dtype=torch.float32)
+        ops.sgat_fwd(xp, att_l.contiguous(), att_r.contiguous(), node_ok, out, alpha, B, M, heads, Cc, bias=bias, out_gelu=act)
+        ctx.save_for_backward(x, w, att_l, att_r, node_ok, xp, alpha, out if gelu else None)
+        ctx.meta = (B, M, heads, Cc, gelu)
+        return act if gelu else out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, att_l, att_r, node_ok, xp, alpha, pre = ctx.saved_tensors
+        B, M, H, Cc, gelu = ctx.meta
+        dev = dy.device
+        dy = dy.contiguous()
+        if gelu:
+            dy = ops.gelu_bwd(dy, pre, torch.empty_like(dy))
+        dbias = torch.zeros(H * Cc, device=dev, dtype=torch.float32)
+        ops.colsum(dy, dbias, R=B * M)
+        dxp = torch.empty_like(xp)
+        dlp, drp = torch.empty(B, H * Cc, device=dev, dtype=torch.float32), torch.empty(B, H * Cc, device=dev, dtype=torch.float32)
+        ops.sgat_bwd(xp, att_l.contiguous(), att_r.contiguous(), node_ok, alpha, dy, dxp, dlp, drp, B, M, H, Cc)
+        dl, dr = torch.zeros(H * Cc, device=dev, dtype=torch.float32), torch.zeros(H * Cc, device=dev, dtype=torch.float32)
+        ops.colsum(dlp, dl, R=B)
+        ops.colsum(drp, dr, R=B)
+        dx, dw = torch.empty_like(x), torch.empty_like(w)
+        ops.small_linear_bwd(dxp, x, w, dx, dw, None)
+        return dx, dw, dl.view_as(att_l), dr.view_as(att_r), dbias, None, None, None
+
+
+class HipSuperGATConv(nn.Module):
+    """``torch_geometric.nn.SuperGATConv(in, out, heads, concat)`` as the reference's fusion_gcn uses it (src/model/baseline.py:14-15),
+    on dense per-sample graphs; parameter names as in torch_geometric 2.x (``lin.weight``, ``att_l``, ``att_r``, ``bias``).
+    PARITY UNPINNED (torch_geometric is absent here and unpinned upstream): restated from the published 'MX' attention."""
+
+    def __init__(self, in_channels: int, out_channels: int, heads: int = 1, concat: bool = True):
+        super().__init__()
+        if not concat and heads != 1:
+            raise NotImplementedError("SuperGATConv(concat=False) is used with one head by the reference; the head mean is not implemented")
+        self.heads, self.out_channels, self.concat = heads, out_channels, concat
+        lin = nn.Module()
+        lin.weight = nn.Parameter(torch.empty(heads * out_channels, in_channels))
+        self.lin = lin
+        self.att_l = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.att_r = nn.Parameter(torch.empty(1, heads, out_channels))
+        self.bias = nn.Parameter(torch.zeros(heads * out_channels))
+        for p in (self.lin.weight, self.att_l, self.att_r):     # glorot, as torch_geometric initialises them
+            nn.init.xavier_uniform_(p)
+
+    def forward(self, x, node_ok, gelu: bool = False):
+        return _SuperGATFn.apply(x, self.lin.weight, self.att_l, self.att_r, self.bias, node_ok.contiguous(), self.heads, gelu)
+
+
+class HipFusionGCN(nn.Module):
+    """``fusion_gcn`` (src/model/baseline.py:11-24): SuperGAT(in, hidden, 4 heads, concat) -> GELU -> SuperGAT(4 hidden, out, 1 head)"""
+
+    def __init__(self, in_channels=256, hidden_dim=128, output_dim=256, heads=4):
+        super().__init__()
+        self.gat1 = HipSuperGATConv(in_channels, hidden_dim, heads=heads, concat=True)
+        self.gat2 = HipSuperGATConv(hidden_dim * heads, output_dim, heads=1, concat=False)
+
+    def forward(self, x, node_ok):
+        """x [B * M, in] (M nodes per sample), node_ok bool [B, M] -> [B * M, out]"""
+        return self.gat2(self.gat1(x, node_ok, gelu=True), node_ok)
+
+
+class _StackFn(torch.autograd.Function):
+    """[B, M * D] row of the modalities' [B, D] blocks (torch.stack(features, dim=1) of the graph heads, src/model/baseline.py:261,300)"""
+
+    @staticmethod
+    def forward(ctx, *xs):
+        _gpu(xs[0], "stack")
+        B, D = xs[0].shape
+        out = torch.empty(B, len(xs) * D, device=xs[0].device, dtype=torch.float32)
+        for i, x in enumerate(xs):
+            ops.masked_copy_block(out[:, i * D:(i + 1) * D], x.contiguous().float(), None, 0)
+        ctx.D = D
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        dout, D = dout.contiguous(), ctx.D
+        outs = []
+        for i in range(dout.shape[1] // D):
+            dx = torch.empty(dout.shape[0], D, device=dout.device, dtype=torch.float32)
+            ops.masked_copy_block(dx, dout[:, i * D:(i + 1) * D], None, 0)
+            outs.append(dx)
+        return tuple(outs)
+
+
+def stack_blocks(xs):
+    return _StackFn.apply(*xs)
+
+
+class _NodeMeanFn(torch.autograd.Function):
+    """mean over the M nodes of every sample: [B * M, D] -> [B, D]   (.view(B, M, -1).mean(dim=-2), src/model/baseline.py:266,322)"""
+
+    @staticmethod
+    def forward(ctx, x, B, M):
+        out = torch.empty(B, x.shape[1], device=x.device, dtype=torch.float32)
+        ops.mean_rows(x.contiguous(), out, B, M, x.shape[1])
+        ctx.M = M
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        M = ctx.M
+        g = (dy * (1.0 / M)).contiguous()                       # (one [B, D] scalar multiply, like the loss's)
+        dx = torch.empty(dy.shape[0], M * dy.shape[1], device=dy.device, dtype=torch.float32)
+        for i in range(M):
+            ops.masked_copy_block(dx[:, i * dy.shape[1]:(i + 1) * dy.shape[1]], g, None, 0)
+        return dx.view(dy.shape[0] * M, dy.shape[1]), None, None
+
+
+def node_mean(x, B, M):
+    return _NodeMeanFn.apply(x, B, M)
+
+
+class _FillMissingFn(torch.autograd.Function):
+    """where(missing == code, filled, x): the unified graph head writes the completion network's output over a missing modality's
+    embedding (src/model/baseline.py:310-312; the reference does it IN PLACE on the encoder output, which is not reproduced)"""
+
+    @staticmethod
+    def forward(ctx, x, filled, missing, code):
+        x, filled = x.contiguous().float(), filled.contiguous()
+        out = torch.empty_like(x)
+        tmp = torch.empty_like(x)
+        ops.masked_copy_block(out, x, missing, code)
+        ops.masked_copy_block(tmp, filled, missing, code, keep_matching=True)
+        ops.add_block(out, tmp)
+        ctx.save_for_backward(missing)
+        ctx.code = code
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        missing, = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx, df = torch.empty_like(dy), torch.empty_like(dy)
+        ops.masked_copy_block(dx, dy, missing, ctx.code)
+        ops.masked_copy_block(df, dy, missing, ctx.code, keep_matching=True)
+        return dx, df, None, None
+
+
+def fill_missing(x, filled, missing_index, code):
+    return _FillMissingFn.apply(x, filled, missing_index.contiguous(), int(code))

@@ -302,13 +302,14 @@ def argmax_rows(ids, out, B, S):
     return out
 
 
-def masked_copy_block(dst, src, row_code, code):
-    """dst = where(row_code == code, 0, src) for two [B, W] views with unit inner stride"""
+def masked_copy_block(dst, src, row_code, code, keep_matching: bool = False):
+    """dst = where(row_code == code, 0, src) for two [B, W] views with unit inner stride (keep_matching: where(..., src, 0))"""
     B, W = src.shape
     if dst.shape != src.shape or dst.stride(1) != 1 or src.stride(1) != 1:
         raise _lib.MissmError("masked_copy_block: bad layout")
     _i64(row_code, "masked_copy_block: row codes")
-    _lib.call("missm_masked_copy_block", dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), B, W, _p(row_code), int(code), _s())
+    _lib.call("missm_masked_copy_block", dst.data_ptr(), dst.stride(0), src.data_ptr(), src.stride(0), B, W, _p(row_code), int(code),
+              int(keep_matching), _s())
 
 
 def add_block(dst, src):
@@ -413,6 +414,37 @@ def preprocess_image(src, dst, *, chw: bool, pre_scale: float, pre_min: float, p
     _lib.call("missm_preprocess_image", src.data_ptr(), int(src.dtype == torch.uint8), int(chw), int(H), int(W), int(Cc), dst.data_ptr(),
               int(dst.shape[1]), float(pre_scale), float(pre_min), float(pre_max), float(pre_div), m3, s3, _s())
     return dst
+
+
+def gelu_bwd(dy, pre, dx):
+    if not (dy.is_contiguous() and pre.is_contiguous() and dx.is_contiguous()) or dy.dtype != torch.float32 or dy.numel() != pre.numel():
+        raise _lib.MissmError("gelu_bwd: fp32 contiguous operands of one size")
+    _lib.call("missm_gelu_bwd", dy.data_ptr(), pre.data_ptr(), dx.data_ptr(), dy.numel(), _s())
+    return dx
+
+
+def sgat_fwd(xp, att_l, att_r, node_ok, out, alpha, B, M, H, Cc, bias=None, out_gelu=None):
+    for t in (xp, att_l, att_r, out, alpha):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.MissmError("sgat_fwd: fp32 contiguous operands")
+    if node_ok.dtype not in (torch.bool, torch.uint8) or node_ok.numel() != B * M or not node_ok.is_contiguous():
+        raise _lib.MissmError("sgat_fwd: node_ok must be a contiguous bool [B, M]")
+    if xp.numel() != B * M * H * Cc or out.numel() != xp.numel() or alpha.numel() != B * H * M * M or att_l.numel() != H * Cc or att_r.numel() != H * Cc:
+        raise _lib.MissmError("sgat_fwd: operand sizes do not match B, M, H, C")
+    if bias is not None and (bias.numel() != H * Cc or bias.dtype != torch.float32 or not bias.is_contiguous()):
+        raise _lib.MissmError("sgat_fwd: bias must be fp32 [H * C]")
+    _lib.call("missm_sgat_fwd", xp.data_ptr(), att_l.data_ptr(), att_r.data_ptr(), node_ok.data_ptr(), _p(bias), out.data_ptr(), _p(out_gelu),
+              alpha.data_ptr(), B, M, H, Cc, _s())
+
+
+def sgat_bwd(xp, att_l, att_r, node_ok, alpha, dout, dxp, dl_part, dr_part, B, M, H, Cc):
+    for t in (xp, att_l, att_r, alpha, dout, dxp, dl_part, dr_part):
+        if t.dtype != torch.float32 or not t.is_contiguous():
+            raise _lib.MissmError("sgat_bwd: fp32 contiguous operands")
+    if dout.numel() != B * M * H * Cc or dxp.numel() != dout.numel() or dl_part.numel() != B * H * Cc or dr_part.numel() != B * H * Cc:
+        raise _lib.MissmError("sgat_bwd: operand sizes do not match B, M, H, C")
+    _lib.call("missm_sgat_bwd", xp.data_ptr(), att_l.data_ptr(), att_r.data_ptr(), node_ok.data_ptr(), alpha.data_ptr(), dout.data_ptr(),
+              dxp.data_ptr(), dl_part.data_ptr(), dr_part.data_ptr(), B, M, H, Cc, _s())
 
 
 def dropout_fwd(x, y, mask, p, seed):

@@ -154,6 +154,61 @@ class modal_inter_attention(_FusionBase):
         return self.head(self.norm(z))
 
 
+class fusion_gcn(hnn.HipFusionGCN):
+    """reference :11-24 (two SuperGAT layers with a GELU between them) on the per-sample modality graphs; see nn.HipSuperGATConv"""
+
+
+def _node_ok(missing_index, modality_types):
+    """bool [B, M]: modality i of sample b is present (the 'missing_modal_index' ones of the reference, :254-258)"""
+    return torch.stack([missing_index != missing_type_index[m] for m in modality_types], dim=1).contiguous()
+
+
+class modal_graph_fusion(_FusionBase):
+    """Graph fusion (reference :240-277): every projected modality is a node, edges join the modalities that are present (plus self
+    loops), two SuperGAT layers, mean over the nodes, LayerNorm, Head.  PARITY UNPINNED: torch_geometric's SuperGATConv is
+    restated (nn.HipSuperGATConv), no reference fixture can be produced here."""
+
+    def __init__(self, args, output_dims):
+        super().__init__(args, output_dims, args.fusion_dim)
+        if args.fusion_dim != 256:
+            raise ValueError("graph_fusion: the reference's fusion_gcn() is built for fusion_dim == 256 (src/model/baseline.py:251)")
+        self.gcn = fusion_gcn()
+
+    def forward(self, batch, missing_index):
+        mt = self.modality_types
+        x = hnn.fused_modal_concat(missing_index, [-1] * len(mt), [batch[m] for m in mt], [self.modal_proj[m] for m in mt])   # [B, M * D], no masking
+        B, M = x.shape[0], len(mt)
+        out = self.gcn(x.view(B * M, -1), _node_ok(missing_index, mt))
+        return self.head(self.norm(hnn.node_mean(out, B, M)))
+
+
+class modal_unified_graph(nn.Module):
+    """Unified GNN (reference :280-331): a completion network over the raw embeddings predicts the missing modality's embedding from
+    the present ones, the filled-in embeddings go through the fusion network on the complete graph; mean over nodes, LayerNorm, Head.
+    PARITY UNPINNED (SuperGATConv restated)."""
+
+    def __init__(self, args, output_dims):
+        super().__init__()
+        self.modality_types = list(args.modality_types)
+        if args.feature_dims != 768 or args.fusion_dim != 256:
+            raise ValueError("unified_graph: the reference's networks are built for feature_dims == 768 and fusion_dim == 256 (:288-289)")
+        self.norm = hnn.HipLayerNorm(args.fusion_dim)
+        self.head = Head(args, args.fusion_dim, output_dims)
+        self.complete_gcn = fusion_gcn(in_channels=768, hidden_dim=384, output_dim=768)
+        self.fusion_gcn = fusion_gcn(in_channels=768)
+
+    def forward(self, batch, missing_index):
+        mt = self.modality_types
+        B, M, D = batch[mt[0]].shape[0], len(mt), batch[mt[0]].shape[1]
+        ok = _node_ok(missing_index, mt)
+        feats = hnn.stack_blocks([batch[m] for m in mt])                                   # [B, M * D]
+        completed = self.complete_gcn(feats.view(B * M, D), ok).view(B, M * D)
+        filled = [hnn.fill_missing(batch[m], completed[:, i * D:(i + 1) * D], missing_index, missing_type_index[m]) for i, m in enumerate(mt)]
+        allf = hnn.stack_blocks(filled)
+        out = self.fusion_gcn(allf.view(B * M, D), torch.ones_like(ok))
+        return self.head(self.norm(hnn.node_mean(out, B, M)))
+
+
 class modal_dedicated_dnn(nn.Module):
     """Dedicated training (reference :333-353): one network over all modalities and one per missing-modality case over the
     remaining ones; every sample is routed to the network of its missing code."""
@@ -247,7 +302,7 @@ class modal_self_distillation(modal_distillation):
         return masks, stu, tea, self.head(self.norm(tea))
 
 
-_NOT_YET = ("graph_fusion", "unified_graph")
+_NOT_YET = ()
 
 
 class finetune_model(nn.Module):
@@ -265,6 +320,10 @@ class finetune_model(nn.Module):
             self.fusion = modal_intra_channel_attention(args, output_dims)
         elif args.fusion_type == "inter_attention":
             self.fusion = modal_inter_attention(args, output_dims)
+        elif args.fusion_type == "graph_fusion":
+            self.fusion = modal_graph_fusion(args, output_dims)
+        elif args.fusion_type == "unified_graph":
+            self.fusion = modal_unified_graph(args, output_dims)
         elif args.fusion_type == "dedicated_dnn":
             self.fusion = modal_dedicated_dnn(args, output_dims)
         elif args.fusion_type == "regression":

@@ -355,6 +355,58 @@ def fusion_inter_attention(emb: Dict[str, Tensor], missing_index: Tensor, fp: Pa
     return head_forward(z, fp)
 
 
+def supergat_conv(x: Tensor, node_ok: Tensor, fp: Params, prefix: str, heads: int, concat: bool, negative_slope: float = 0.2) -> Tensor:
+    """``torch_geometric.nn.SuperGATConv(in, out, heads, concat)`` (attention_type 'MX', add_self_loops) as ``fusion_gcn`` uses it
+    (src/model/baseline.py:14-15,19-21), on the dense per-sample modality graphs the heads build (``bulid_edge`` :270-277: edges in
+    both directions between modalities that are present; the convolution adds self loops).  PARITY UNPINNED: torch_geometric is
+    absent from this image and unpinned upstream; restated from the published algorithm (Kim & Oh, ICLR 2021, 'MX' attention:
+    e_ij = (a_l . Wx_j + a_r . Wx_i) * sigmoid(Wx_i . Wx_j), leaky_relu, softmax over the incoming edges, sum_j alpha_ij Wx_j, bias).
+    x [B, M, in], node_ok bool [B, M] -> [B, M, heads * out] (concat) or [B, M, out] (mean over heads)."""
+    B, M, _ = x.shape
+    W, al, ar, bias = fp[prefix + ".lin.weight"], fp[prefix + ".att_l"], fp[prefix + ".att_r"], fp[prefix + ".bias"]
+    C = W.shape[0] // heads
+    xp = F.linear(x, W).view(B, M, heads, C)
+    logits = torch.einsum("bihc,bjhc->bijh", xp, xp)
+    a = (xp * al).sum(-1)[:, None, :, :] + (xp * ar).sum(-1)[:, :, None, :]          # [B, i (target), j (source), H]
+    a = F.leaky_relu(a * torch.sigmoid(logits), negative_slope)
+    eye = torch.eye(M, dtype=torch.bool)[None]
+    edge = eye | (node_ok[:, :, None] & node_ok[:, None, :])
+    a = a.masked_fill(~edge[..., None], float("-inf"))
+    alpha = torch.softmax(a, dim=2)
+    out = torch.einsum("bijh,bjhc->bihc", alpha, xp)
+    out = out.reshape(B, M, heads * C) if concat else out.mean(dim=2)
+    return out + bias
+
+
+def fusion_gcn(x: Tensor, node_ok: Tensor, fp: Params, prefix: str, heads: int = 4) -> Tensor:
+    """``fusion_gcn.forward`` src/model/baseline.py:18-24: SuperGAT (4 heads, concat) -> exact GELU -> SuperGAT (1 head, mean)."""
+    h = F.gelu(supergat_conv(x, node_ok, fp, prefix + ".gat1", heads, True))
+    return supergat_conv(h, node_ok, fp, prefix + ".gat2", 1, False)
+
+
+def fusion_graph(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                 codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_graph_fusion.forward`` src/model/baseline.py:253-268 (PARITY UNPINNED through supergat_conv)."""
+    x = torch.stack([F.linear(emb[m], fp[f"modal_proj.{m}.weight"], fp[f"modal_proj.{m}.bias"]) for m in modality_types], dim=1)
+    ok = torch.stack([missing_index != codes[m] for m in modality_types], dim=1)
+    z = fusion_gcn(x, ok, fp, "gcn").mean(dim=-2)
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
+def fusion_unified_graph(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
+                         codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
+    """``modal_unified_graph.forward`` src/model/baseline.py:291-324 (PARITY UNPINNED through supergat_conv): a completion network
+    fills the missing modality's embedding, the fusion network runs on the complete graph."""
+    x = torch.stack([emb[m] for m in modality_types], dim=1)
+    miss = torch.stack([missing_index == codes[m] for m in modality_types], dim=1)
+    done = fusion_gcn(x, ~miss, fp, "complete_gcn")
+    x = torch.where(miss[..., None], done, x)
+    z = fusion_gcn(x, torch.ones_like(miss), fp, "fusion_gcn").mean(dim=-2)
+    z = F.layer_norm(z, (z.shape[-1],), fp["norm.weight"], fp["norm.bias"], 1e-5)
+    return head_forward(z, fp)
+
+
 def fusion_dedicated_dnn(emb: Dict[str, Tensor], missing_index: Tensor, fp: Params, modality_types: Sequence[str],
                          codes: Dict[str, int] = MISSING_TYPE_INDEX) -> Tensor:
     """``modal_dedicated_dnn.forward`` src/model/baseline.py:345-353: full network on the concatenated embeddings; rows whose

@@ -1,0 +1,36 @@
+"""Attention fwd / bwd micro-benchmark at the video tower's spatial shape (256 frames x 12 heads, S = 197) and the grouped image
+towers' (128 frames): time per launch, achieved algorithmic GB/s and TFLOP/s."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from missm_benchmark_amd import ops
+
+
+def timed(fn, iters=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters
+
+
+for nseq in (256, 128, 32):
+    L, H, hd = 197, 12, 64
+    rows = nseq * L
+    qkv = (torch.randn(rows, 3 * H * hd, device="cuda") * 0.5).to(torch.bfloat16)
+    out = torch.empty(rows, H * hd, device="cuda", dtype=torch.bfloat16)
+    lse = torch.empty(nseq * H * L, device="cuda")
+    dout = torch.randn(rows, H * hd, device="cuda").to(torch.bfloat16)
+    dqkv = torch.empty_like(qkv)
+    f = timed(lambda: ops.attention_fwd(qkv, out, lse, nseq, L, H, hd))
+    b = timed(lambda: ops.attention_bwd(qkv, out, dout, lse, dqkv, nseq, L, H, hd))
+    units = nseq * H
+    fb, bb = units * L * hd * 4 * 2, units * L * hd * 8 * 2
+    ff, bf = 4.0 * units * L * L * hd, 10.0 * units * L * L * hd
+    print(f"nseq {nseq:4d}: fwd {f*1e3:7.1f} us ({fb/f/1e6:6.0f} GB/s, {ff/f/1e9:6.1f} TFLOP/s, {f*1e3/units*256:5.2f} us per unit-CU)   "
+          f"bwd {b*1e3:7.1f} us ({bb/b/1e6:6.0f} GB/s, {bf/b/1e9:6.1f} TFLOP/s, {b*1e3/units*256:5.2f} us per unit-CU)", flush=True)
