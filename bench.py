@@ -53,12 +53,12 @@ def parse():
 
 def gemm_traffic(launches_per_step):
     """HBM-side bytes per GEMM launch (one `missm_gemm` call: the tile kernel(s) + the split-K reduce) from the committed PMC
-    passes (profiles/r01_pmc_hbm_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate rocprofv3
+    passes (profiles/r02_pmc_hbm_traffic.json: FETCH_SIZE doubled per the gfx950 correction + WRITE_SIZE, separate rocprofv3
     --pmc runs of this script with --serial-streams, tools/pmc_traffic.py); None if absent or for another workload."""
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_hbm_traffic.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_hbm_traffic.json")))
         return {"bytes_per_launch": int(d["kernels"]["gemm"]["bytes_per_step"] / launches_per_step), "unit": "B",
-                "source": "profiles/r01_pmc_hbm_traffic.json"}
+                "source": "profiles/r02_pmc_hbm_traffic.json"}
     except Exception:
         return None
 
@@ -299,7 +299,7 @@ def main():
                 print(f"[gemm] M,N,K,tA,tB,act={shape}: {n:4d} launches {t:8.2f} ms  {f / t / 1e9:7.1f} TFLOP/s", file=sys.stderr)
         ach = flops / (ms * 1e-3) / 1e12
         default_workload = set(modalities) == set(MODALITIES) and B == 32 and args.dtype == "bf16"   # what the PMC passes ran
-        roof = {"kernel": "gemm_kernel<bf16,TA,TB,128,VAR> (the MFMA GEMM behind every linear, dX and dW)" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
+        roof = {"kernel": "gemm8p_kernel / gemm8p_tn_kernel (+ gemm_kernel<bf16,..> on small shapes): the MFMA GEMM family behind every linear, dX and dW" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                 "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                 "traffic": gemm_traffic(len(prof) / (args.steps if inline_prof else 2)) if default_workload else None,

@@ -19,7 +19,9 @@ def timed(fn, iters=20):
     return e0.elapsed_time(e1) / iters
 
 
-for nseq in (256, 128, 32):
+NSEQ = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (256, 128, 32)
+ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+for nseq in NSEQ:
     L, H, hd = 197, 12, 64
     rows = nseq * L
     qkv = (torch.randn(rows, 3 * H * hd, device="cuda") * 0.5).to(torch.bfloat16)
@@ -27,8 +29,8 @@ for nseq in (256, 128, 32):
     lse = torch.empty(nseq * H * L, device="cuda")
     dout = torch.randn(rows, H * hd, device="cuda").to(torch.bfloat16)
     dqkv = torch.empty_like(qkv)
-    f = timed(lambda: ops.attention_fwd(qkv, out, lse, nseq, L, H, hd))
-    b = timed(lambda: ops.attention_bwd(qkv, out, dout, lse, dqkv, nseq, L, H, hd))
+    f = timed(lambda: ops.attention_fwd(qkv, out, lse, nseq, L, H, hd), ITERS)
+    b = timed(lambda: ops.attention_bwd(qkv, out, dout, lse, dqkv, nseq, L, H, hd), ITERS)
     units = nseq * H
     fb, bb = units * L * hd * 4 * 2, units * L * hd * 8 * 2
     ff, bf = 4.0 * units * L * L * hd, 10.0 * units * L * L * hd

@@ -24,10 +24,10 @@ def load(path, counter):
 STEPS = 2   # --steps 1 --warmup 1
 f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 1 "
-                  "--no-cpu-baseline --no-roofline --serial-streams",
+                  "--no-cpu-baseline --no-roofline --no-fp32-line --serial-streams",
        "note": "2 steps profiled (1 warm-up + 1 timed). FETCH_SIZE in KiB, doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
-               "coalesced reads); WRITE_SIZE in KiB.  gemm = gemm_kernel (both tile shapes) + splitk_reduce_kernel; its launches count "
-               "gemm_kernel dispatches only.", "kernels": {}}
+               "coalesced reads); WRITE_SIZE in KiB.  gemm = gemm8p_kernel + gemm8p_tn_kernel + gemm_kernel + the split-K reduce kernels; its "
+               "launches count the tile-kernel dispatches only (a grouped launch is one dispatch).", "kernels": {}}
 for fam in sorted(set(f.fam)):
     ff, ww = f[f.fam == fam], w[w.fam == fam]
     n = int(ff.is_gemm.sum()) if fam == "gemm" else len(ff)
