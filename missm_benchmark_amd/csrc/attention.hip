@@ -35,6 +35,11 @@ __device__ __forceinline__ size_t seq_base(const AttnArgs& a, int q) {
 constexpr int HD = 64;
 constexpr int ANW = 8;            // waves per MFMA-attention workgroup (512 threads): query / key tiles are dealt round-robin
 constexpr int ATHREADS = ANW * 64;
+// Waves of a whole-workgroup unit.  S = 197 has 13 tiles in 14 slots: 8 waves hold 2,2,2,2,2,1,1,1 tiles, 7 waves would hold
+// 2,2,2,2,2,2,1 - measured SLOWER (fwd 78 -> 85 us, bwd 272 -> 294 us at 256 frames x 12 heads): the kernels are bound by
+// per-wave latency (47 % of wave cycles parked on s_waitcnt, 32 % on issue dependencies, profiles/r02_attn_sq_counters.txt),
+// so the extra resident waves are worth more than the balance.
+constexpr int attn_waves(int ntp) { (void)ntp; return ANW; }
 constexpr float kNegInf = -__builtin_huge_valf();
 
 __device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4];   // source of zero-filled LDS chunks
@@ -91,12 +96,12 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_fwd_mfm
   const T* qkv = static_cast<const T*>(a.qkv);
   const int L = a.L;
   const float sl2 = a.scale * 1.4426950408889634f;   // scale * log2(e)
-  constexpr int NWV = PW ? 1 : ANW;           // waves cooperating on one unit
+  constexpr int NWV = PW ? 1 : attn_waves(NTP);   // waves cooperating on one unit
   const int wv = PW ? 0 : wave;               // this wave's index among them
 
   stage_head<T, RBv, NWV>(ldsK, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wv);
   stage_head<T, RBv, NWV>(ldsV, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, lane, wv);
-  for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS)
+  for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : NWV * 64)
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
 
   // Q fragments of every query tile this wave owns are fetched while the K/V pieces are still in flight
@@ -209,7 +214,12 @@ __device__ __forceinline__ float frag_dot(f32x4 x, f32x4 y, float s) { return s 
 // the probabilities / score gradients of a tile row can then be packed into MFMA operand fragments as they are produced,
 // two 16-key tiles at a time, instead of living in 2 x NTP fp32 tiles until the row sum is known - 216 -> <= 128 VGPRs at
 // S = 197, i.e. two 8-wave workgroups per CU instead of one.
-template <typename T, int NTP, bool PW, bool CAUSAL>
+//
+// MASK / FULL as in the forward: with FULL (L > 16 (NTP - 2)) and no key mask the first NTP - 2 tiles of either pass carry no
+// run-time condition, so the tile loop is straight-line code the compiler can schedule ACROSS tiles.  The conditional version
+// issued every tile as  ds_read -> wait -> 2 dependent MFMAs -> branch -> exp -> branch  with nothing of the next tile in flight:
+// 47 % of the wave cycles parked on s_waitcnt, 32 % on issue dependencies (profiles/r02_attn_sq_counters.txt).
+template <typename T, int NTP, bool PW, bool CAUSAL, bool MASK = true, bool FULL = false>
 __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfma_kernel(AttnArgs a) {
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
@@ -231,7 +241,7 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
   const int unit = PW ? blockIdx.x * ANW + wave : blockIdx.x;
   if (PW && unit >= a.nseq * a.H) return;
   const int seq = unit / a.H, h = unit % a.H;
-  constexpr int NWV = PW ? 1 : ANW;
+  constexpr int NWV = PW ? 1 : attn_waves(NTP);
   const int wv = PW ? 0 : wave;
   const size_t base = seq_base(a, seq);
   const T* qkv = static_cast<const T*>(a.qkv);
@@ -242,11 +252,11 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
   const float sl2 = a.scale * 1.4426950408889634f;   // scale * log2(e)
   const float inv_scale = 1.0f / a.scale;             // lse / scale goes into LDS: it is the score accumulators' initial value
   const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
-  const bool any_mask = a.key_mask != nullptr;
+  constexpr int NFULL = (FULL && !PW) ? NTP - 2 : 0;   // tiles (keys in pass A, queries in pass B) known to be full
 
   stage_head<T, RBv, NWV>(X0, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wv);
   stage_head<T, RBv, NWV>(X1, qkv, base, a.tok_stride, a.ld, 2 * a.d + h * HD, L, LP, lane, wv);
-  for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : ATHREADS) {
+  for (int k = PW ? lane : tid; k < LP; k += PW ? 64 : NWV * 64) {
     kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
     lseL[k] = k < L ? lse[k] * inv_scale : __builtin_huge_valf();
   }
@@ -320,12 +330,12 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
     for (int dt = 0; dt < HD / 16; ++dt) dqa[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      if (u * CT >= nt) continue;             // (wave-uniform) no key in this step
+      if (u * CT >= NFULL && u * CT >= nt) continue;             // (wave-uniform) no key in this step
       f32x4 dsv[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int kt = u * CT + c;
-        if (kt >= nt) { dsv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
+        if (kt >= NFULL && kt >= nt) { dsv[c] = f32x4{0.f, 0.f, 0.f, 0.f}; continue; }
         f32x4 sc = {nlq, nlq, nlq, nlq}, dp = {ndsum, ndsum, ndsum, ndsum};
 #pragma unroll
         for (int ks = 0; ks < KSQ; ++ks) {
@@ -333,7 +343,7 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
           sc = M_::step(lds_frag<T>(X0, off), qf[ks], sc);
           dp = M_::step(lds_frag<T>(X1, off), dof[ks], dp);
         }
-        if (any_mask || kt * 16 + 16 > L) sc += *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);   // (-inf on masked keys)
+        if (MASK || kt >= NFULL) sc += *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);   // (-inf on masked / padded keys)
         // (the softmax scale is applied once to the dQ / dK accumulators instead of to every dS element)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -393,19 +403,18 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
         }
       }
     }
-    const bool use_kb = any_mask || kt * 16 + 16 > L;      // wave-uniform: this wave's key tile may hold a masked / padded key
-    const float kb = use_kb ? kbias[key] : 0.f;
+    const float kb = kbias[key];               // 0, or -inf on a masked / padded key: rides in the exp2's multiply-add
     f32x4 dva[HD / 16], dka[HD / 16];          // dV^T / dK^T of this key tile, accumulated query step by query step
 #pragma unroll
     for (int dt = 0; dt < HD / 16; ++dt) { dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dka[dt] = dva[dt]; }
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
-      if (u * CT >= nt) continue;             // (wave-uniform) no query in this step
+      if (u * CT >= NFULL && u * CT >= nt) continue;             // (wave-uniform) no query in this step
       f32x4 pv4[CT], dsv[CT];
 #pragma unroll
       for (int c = 0; c < CT; ++c) {
         const int qt = u * CT + c;
-        if (qt >= nt) { pv4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dsv[c] = pv4[c]; continue; }     // query tile without any query
+        if (qt >= NFULL && qt >= nt) { pv4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dsv[c] = pv4[c]; continue; }     // query tile without any query
         // initial accumulators: -lse / scale and -D of the tile's 4 query rows this lane holds (see pass A)
         f32x4 sc = -*reinterpret_cast<const f32x4*>(lseL + qt * 16 + 4 * lg);
         f32x4 dp = -*reinterpret_cast<const f32x4*>(Dl + qt * 16 + 4 * lg);
@@ -417,7 +426,7 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float pv = __builtin_amdgcn_exp2f(use_kb ? sc[r] * sl2 + kb : sc[r] * sl2);
+          float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kb);
           if constexpr (CAUSAL) { if (key > qt * 16 + 4 * lg + r) pv = 0.f; }
           pv4[c][r] = pv;
           dsv[c][r] = pv * dp[r];
@@ -671,7 +680,7 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
     return missm_check_launch("attn_small");
   }
   if (hd != HD || L > 256) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64 and L<=256)", L, hd); return MISSM_ERR_INVALID; }
-  dim3 grid(a.nseq * a.H), block(ATHREADS);
+  dim3 grid(a.nseq * a.H);
   // forward specialisations: FULL when every key tile but the last two is full (L > 16 (NTP - 2): S = 197 / NTP 14, S = 77 / NTP 6),
   // MASK when a key_padding_mask (or causality, which always comes with one here) can hit any tile
   const bool mask = a.key_mask != nullptr || a.causal;
@@ -679,8 +688,14 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
   do {                                                                                                      \
     size_t shmem = (size_t)2 * NTP * 16 * HD * sizeof(T) + (size_t)NTP * 16 * 4 * (BWD ? 3 : 1);              \
     const bool full = L > 16 * (NTP - 2);                                                                   \
+    const dim3 block(attn_waves(NTP) * 64);                                                                 \
     if constexpr (BWD) {                                                                                    \
-      auto k = a.causal ? attn_bwd_mfma_kernel<T, NTP, false, true> : attn_bwd_mfma_kernel<T, NTP, false, false>;          \
+      /* (the straight-line FULL variants are bf16 only: the fp32 instantiation spills under them) */       \
+      constexpr bool FB = sizeof(T) == 2;                                                                   \
+      auto k = a.causal ? attn_bwd_mfma_kernel<T, NTP, false, true>                                          \
+               : (FB && full && !mask) ? attn_bwd_mfma_kernel<T, NTP, false, false, false, FB>                \
+               : (FB && full) ? attn_bwd_mfma_kernel<T, NTP, false, false, true, FB>                          \
+                              : attn_bwd_mfma_kernel<T, NTP, false, false>;                                   \
       int rc = launch_dyn(k, grid, block, shmem, s, "attn_mfma"); if (rc) return rc;                          \
       hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                       \
     } else {                                                                                                \

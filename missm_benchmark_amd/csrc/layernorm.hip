@@ -95,7 +95,10 @@ struct LnBwdArgs {
   void* dx_cast;         // optional Tin copy of the updated dx rows (GEMM operand of the next backward block)
 };
 
-template <typename Tin, int CH>
+// FAST: cols == CH * 256, accumulate, dx_cast and no row gather - the residual-stream LayerNorms of every tower layer.  With the
+// column guards and the uniform branches gone the loop is straight-line code, so the compiler can COUNT the memory operations:
+// it waits for the prefetched row with vmcnt(#stores issued after it) instead of vmcnt(0) on the stores' write acknowledgements.
+template <typename Tin, int CH, bool FAST = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
   __shared__ float red[2][4][CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -106,30 +109,47 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int col = (c * 64 + lane) * 4;
-    gm[c] = col < a.cols ? load4(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    gm[c] = (FAST || col < a.cols) ? load4(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   const float inv = 1.0f / a.cols;
-  for (int row = blockIdx.x * 4 + wave; row < a.rows; row += gridDim.x * 4) {
-    const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
+  // One row per wave per trip, software-pipelined: the NEXT row's x / dy / running-gradient loads are issued before this row's
+  // two reductions and stores, so a wave always has a row in flight (one row at a time left the memory pipe idle through every
+  // reduce -> store -> address -> load turn-around: 4.3 TB/s; the registers for the second row are free at 3 waves per SIMD).
+  using DyRaw = std::conditional_t<std::is_same<Tin, float>::value, f32x4, bf16x4>;   // kept unconverted while in flight
+  f32x4 nx[CH], nprev[CH];
+  DyRaw ndy[CH];
+  float nmean = 0.f, nrstd = 0.f;
+  auto issue = [&](int row) {
+    const size_t irow = (size_t)row * a.in_mul + ((!FAST && a.in_off) ? a.in_off[row] : 0);
     const float* xr = a.x + irow * a.cols;
+    const float* pr = a.dx + irow * a.cols;
     const Tin* dyr = static_cast<const Tin*>(a.dy) + (size_t)(row / a.dy_div) * a.cols;
-    const float mean = a.mean[row], rstd = a.rstd[row];
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if ((FAST || col < a.cols)) {
+        nx[c] = load4(xr + col);
+        ndy[c] = *reinterpret_cast<const DyRaw*>(dyr + col);
+        if (FAST || a.accumulate) nprev[c] = load4(pr + col);
+      }
+    }
+    nmean = a.mean[row]; nrstd = a.rstd[row];
+  };
+  const int row0 = blockIdx.x * 4 + wave, rstep = gridDim.x * 4;
+  if (row0 < a.rows) issue(row0);
+  for (int row = row0; row < a.rows; row += rstep) {
+    const size_t irow = (size_t)row * a.in_mul + ((!FAST && a.in_off) ? a.in_off[row] : 0);
+    const float mean = nmean, rstd = nrstd;
     f32x4 xh[CH], g[CH], prev[CH];
     float s1 = 0.f, s2 = 0.f;
     float* dxr = a.dx + irow * a.cols;
-    // the running residual gradient this row's result is added to is requested together with x and dy (it used to be loaded
-    // after the two row reductions: a second memory round trip per row with nothing else in flight in the wave)
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int col = (c * 64 + lane) * 4;
-      prev[c] = (a.accumulate && col < a.cols) ? load4(dxr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int c = 0; c < CH; ++c) {
-      const int col = (c * 64 + lane) * 4;
-      if (col < a.cols) {
-        const f32x4 xv = load4(xr + col);
-        f32x4 d = load4(dyr + col);
+      prev[c] = ((FAST || a.accumulate) && (FAST || col < a.cols)) ? nprev[c] : f32x4{0.f, 0.f, 0.f, 0.f};
+      if ((FAST || col < a.cols)) {
+        const f32x4 xv = nx[c];
+        f32x4 d = {(float)ndy[c][0], (float)ndy[c][1], (float)ndy[c][2], (float)ndy[c][3]};
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           d[j] *= a.dy_scale;
@@ -144,18 +164,19 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
         xh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
+    if (row + rstep < a.rows) issue(row + rstep);
     s1 = wave_sum(s1) * inv;
     s2 = wave_sum(s2) * inv;
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int col = (c * 64 + lane) * 4;
-      if (col < a.cols) {
+      if ((FAST || col < a.cols)) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = rstd * (g[c][j] - s1 - xh[c][j] * s2);
         o += prev[c];
         store4(dxr + col, o);
-        if (a.dx_cast) store4(static_cast<Tin*>(a.dx_cast) + irow * a.cols + col, o);
+        if (FAST || a.dx_cast) store4(static_cast<Tin*>(a.dx_cast) + irow * a.cols + col, o);
       }
     }
   }
@@ -231,7 +252,9 @@ extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, c
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_ch<void>(cols, [&](auto ch) {
     constexpr int CH = decltype(ch)::value;
-    if (dy_dtype == kBF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16, CH>), grid, block, 0, s, a);
+    const bool fast = cols == CH * 256 && accumulate && dx_cast && !in_off;
+    if (dy_dtype == kBF16 && fast) hipLaunchKernelGGL((ln_bwd_kernel<bf16, CH, true>), grid, block, 0, s, a);
+    else if (dy_dtype == kBF16) hipLaunchKernelGGL((ln_bwd_kernel<bf16, CH>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((ln_bwd_kernel<float, CH>), grid, block, 0, s, a);
     return MISSM_OK;
   });
