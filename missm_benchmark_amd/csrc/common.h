@@ -71,9 +71,14 @@ template <int RB> __device__ __forceinline__ int swz(int row, int byte_in_row) {
 }
 
 // quick_gelu(x) = x * sigmoid(1.702 x) and its derivative
-__device__ __forceinline__ float quick_gelu(float x) { return x / (1.0f + __expf(-1.702f * x)); }
+// sigmoid through ONE v_exp_f32 and ONE v_rcp_f32 (1 ulp each): an IEEE `1.0f / y` is a 10-instruction div_scale / rcp / fma /
+// div_fmas / div_fixup sequence, which made the activation epilogues of the 256x256 GEMM tile VALU-bound (128 values per lane)
+__device__ __forceinline__ float sigmoid_1702(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(x * (-1.702f * 1.4426950408889634f)));
+}
+__device__ __forceinline__ float quick_gelu(float x) { return x * sigmoid_1702(x); }
 __device__ __forceinline__ float quick_gelu_grad(float x) {
-  float s = 1.0f / (1.0f + __expf(-1.702f * x));
+  const float s = sigmoid_1702(x);
   return s + 1.702f * x * s * (1.0f - s);
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }

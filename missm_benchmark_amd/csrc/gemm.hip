@@ -890,6 +890,15 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
   MISSM_CHECK_ARG(!(resid && !out_f32) && !(accumulate && !out_f32), "gemm: resid/accumulate need out_f32");
   MISSM_CHECK_ARG(((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0), "gemm: unaligned operand");
   MISSM_CHECK_ARG(!bias || ((uintptr_t)bias % 16 == 0), "gemm: bias must be 16-byte aligned");
+  // MISSM_GEMM_LOG=<file>: one line per tile-kernel dispatch, in launch order - tools/gemm_insitu.py joins it with a rocprofv3
+  // kernel trace for the per-shape time INSIDE the training step.
+  static FILE* shape_log = getenv("MISSM_GEMM_LOG") ? fopen(getenv("MISSM_GEMM_LOG"), "w") : nullptr;
+  auto log_shape = [&](int m_eff) {
+    if (!shape_log) return;
+    fprintf(shape_log, "%d %d %d %d %d %d %d %d %d %d %d %d %d\n", m_eff, N, K, trans_a, trans_b, act, out_f32, resid != nullptr,
+            aux_in != nullptr, aux_out != nullptr, colsum_a != nullptr, accumulate, ngroups > 1 ? ngroups : 1);
+    fflush(shape_log);
+  };
   GemmArgs g;
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
@@ -973,6 +982,7 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
       }
       attr_tn[use8p_tn == 2] = true;
     }
+    log_shape(M);
     hipLaunchKernelGGL(kt, dim3(g.ngroups * t2 * sp), dim3(512), 128 * 1024, s, g);
     hipLaunchKernelGGL(splitk_reduce8p_kernel, dim3(g.ngroups * t2 * 8), dim3(512), 0, s, g);
     return missm_check_launch("gemm8p_tn");
@@ -1032,10 +1042,12 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
           ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         const int nwg = persist ? (tmb * tn2 < ncu ? tmb * tn2 : ncu) : tmb * tn2;
+        log_shape(g.M);
         hipLaunchKernelGGL(k8, dim3(nwg), dim3(512), 128 * 1024, s, g);
         return missm_check_launch("gemm8p");
       }
       if (ngroups > 1) return MISSM_GROUPED_UNAVAILABLE;
+      log_shape(g.M);
       auto k = gemm_kernel<bf16, false, false, 128, 1, 4>;
       static bool attr_set = false;
       if (!attr_set) {
@@ -1072,6 +1084,7 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
     else if (var == 2) hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128, 2>), grid, block, 64 * 1024, s, g);  \
     else hipLaunchKernelGGL((gemm_kernel<T, TA, TB, 128>), grid, block, 64 * 1024, s, g);                   \
   } while (0)
+  log_shape(M);
   if (dtype == kBF16) {
     if (!trans_a && !trans_b) MISSM_GEMM_LAUNCH(bf16, false, false);
     else if (!trans_a && trans_b) MISSM_GEMM_LAUNCH(bf16, false, true);

@@ -78,6 +78,124 @@ __device__ __forceinline__ void gemm8p_prologue(char* lds, const Gemm8pSrc& src,
   stage_half<6, 2>(lds, src, wave, 128, nt > 1);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Branch-free vector epilogue of the 8-phase tile.  gemm_epilogue (gemm.hip) guards every row with `row < M`: sixteen exec
+// branches per 64 x 64 block, which also pin every dependent load (saved pre-activation, fp32 residual) directly in front of
+// its use - the backward-through-activation epilogue took as long as the main loop (17 us of a 34 us tile, in-kernel stamps).
+// Here C / aux / residual are addressed through range-checked buffer descriptors that span exactly the wave's valid rows
+// (rows past M: loads return 0, stores are dropped), so the block is straight-line code: all loads of a block are issued
+// before the first use, stores follow back to back.  A lane owns rows 4 lg + r of each 16-row tile i and 4 consecutive columns.
+// Row (ha, i, r) is a SCALAR offset (128 ha + 16 i + r) * row pitch; the lane offset is one VGPR per matrix.
+// ---------------------------------------------------------------------------------------------------------------------
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+
+struct Epi8p {
+  __amdgpu_buffer_rsrc_t c, aux, res;
+  unsigned vc, vaux;           // per-lane byte offsets (C / residual share one, the bf16 aux matrix has its own pitch)
+  unsigned pitch_c, pitch_aux; // row pitch in bytes
+};
+
+__device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) {
+  bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
+  return __builtin_bit_cast(u32x2, r);
+}
+__device__ __forceinline__ f32x4 unpack_bf16x4(u32x2 w) {
+  const bf16x4 r = __builtin_bit_cast(bf16x4, w);
+  return f32x4{(float)r[0], (float)r[1], (float)r[2], (float)r[3]};
+}
+
+// MODE 0: bf16 = acc * alpha + bias            1: + QuickGELU, pre-activation saved to aux (if any)
+//      2: bf16 = (acc * alpha + bias) * QuickGELU'(aux)             3: fp32 = acc * alpha + bias (+ residual)
+template <int MODE>
+__device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bool has_res, float alpha, f32x4 bias4,
+                                                const f32x4 (&acc)[2][2][4][2]) {
+#define MISSM_VAL(ha, i, r)                                                                                            \
+  f32x4{acc[ha][0][i][0][r] * alpha + bias4[0], acc[ha][0][i][1][r] * alpha + bias4[1],                               \
+        acc[ha][1][i][0][r] * alpha + bias4[2], acc[ha][1][i][1][r] * alpha + bias4[3]}
+  // address = lane offset of row r (4 VGPRs per matrix) + SCALAR offset of the 16-row tile (ha, i): 8 scalars per matrix
+  unsigned vcr[4], var[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { vcr[r] = e.vc + r * e.pitch_c; var[r] = e.vaux + r * e.pitch_aux; }
+#define MISSM_SC(ha, i) ((128 * (ha) + 16 * (i)) * e.pitch_c)
+#define MISSM_SA(ha, i) ((128 * (ha) + 16 * (i)) * e.pitch_aux)
+  if constexpr (MODE == 2) {
+    // pre-activation rows in chunks of two 16-row tiles (8 loads, 16 VGPRs), two chunks in flight: the next chunk is requested
+    // before this one is used, so only the first request's latency is exposed
+    u32x2 u[2][8];
+    auto request = [&](int ch, u32x2 (&dst)[8]) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int ha = ch >> 1, i = 2 * (ch & 1) + (k >> 2), r = k & 3;
+        dst[k] = __builtin_amdgcn_raw_buffer_load_b64(e.aux, var[r], MISSM_SA(ha, i), 0);
+      }
+    };
+    request(0, u[0]);
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) {
+      if (ch + 1 < 4) request(ch + 1, u[(ch + 1) & 1]);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const int ha = ch >> 1, i = 2 * (ch & 1) + (k >> 2), r = k & 3;
+        f32x4 v = MISSM_VAL(ha, i, r);
+        const f32x4 uu = unpack_bf16x4(u[ch & 1][k]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(uu[j]);
+        __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), 0);
+      }
+    }
+  } else if constexpr (MODE == 3) {
+    if (has_res) {
+      // residual rows in chunks of one 16-row tile (4 loads, 16 VGPRs), two chunks in flight
+      u32x4 q[2][4];
+      auto request = [&](int ch, u32x4 (&dst)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(e.res, vcr[r], MISSM_SC(ch >> 2, ch & 3), 0);
+      };
+      request(0, q[0]);
+#pragma unroll
+      for (int ch = 0; ch < 8; ++ch) {
+        if (ch + 1 < 8) request(ch + 1, q[(ch + 1) & 1]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x4 v = MISSM_VAL(ch >> 2, ch & 3, r);
+          v += __builtin_bit_cast(f32x4, q[ch & 1][r]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ch >> 2, ch & 3), 0);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const f32x4 v = MISSM_VAL(ha, i, r);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ha, i), 0);
+          }
+    }
+  } else {
+#pragma unroll
+    for (int ha = 0; ha < 2; ++ha)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          f32x4 v = MISSM_VAL(ha, i, r);
+          if constexpr (MODE == 1) {
+            if (has_aux) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.aux, var[r], MISSM_SA(ha, i), 0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
+          }
+          __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), 0);
+        }
+  }
+#undef MISSM_VAL
+#undef MISSM_SC
+#undef MISSM_SA
+}
+
 // STAGGER: waves 4-7 run one barrier behind waves 0-3.
 // The grid is PERSISTENT (one workgroup per CU walks tiles bid, bid + gridDim.x, ...): once a tile's main loop has ended every
 // LDS slot is free, so the next tile's first seven half tiles are requested BEFORE this tile's epilogue - their 1.5-2.4 us of
@@ -246,30 +364,49 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
 
   // ---- epilogue: two 64 x 64 blocks per wave (A half 0 / 1), a lane owns rows 4 lg + r of each 16-row tile and the four
   // consecutive columns 64 wc + 4 li + {0, 1 (B half 0), 2, 3 (B half 1)}: the same register picture as gemm_kernel's.
-  // backward-through-activation epilogue: the saved pre-activations (4 consecutive columns x 32 rows per lane) are requested
-  // for BOTH blocks at once, before any of them is used - one load per use left the wave waiting out a memory round trip
-  // thirty-two times (24 us of a 42 us tile, in-kernel stamps).  The fragment registers are free by now.
-  const bool have_upre = g.act == MISSM_ACT_DQGELU && !g.out_f32 && g.vec_ok && !g.accumulate && n0 + 64 * wc + 64 <= g.N;
+  {
+    const int mwb = m0 + 64 * wr, nw = n0 + 64 * wc;
+    const int esz = g.out_f32 ? 4 : 2;
+    const int mode = g.out_f32 ? (g.act == MISSM_ACT_NONE ? 3 : -1)
+                               : (g.act == MISSM_ACT_NONE ? 0 : (g.act == MISSM_ACT_QGELU ? 1 : (g.act == MISSM_ACT_DQGELU ? 2 : -1)));
+    const void* auxp = mode == 1 ? g.aux_out : (mode == 2 ? g.aux_in : nullptr);
+    const bool has_aux = auxp != nullptr;
+    // (buffer offsets are 32-bit: matrices of 4 GiB and more keep the guarded epilogue)
+    const bool fast = mode >= 0 && g.vec_ok && !g.accumulate && nw + 64 <= g.N && (mode != 2 || has_aux) && (mode == 3 || !g.resid) &&
+                      (size_t)g.M * g.ldc * esz < (size_t(1) << 32) && (size_t)g.M * g.ldaux * 2 < (size_t(1) << 32);
+    if (fast) {
+      Epi8p e;
+      e.pitch_c = (unsigned)g.ldc * esz; e.pitch_aux = (unsigned)g.ldaux * 2u;
+      const unsigned rows = (unsigned)min(max(g.M - mwb, 0), 192);
+      char* cb = static_cast<char*>(g.C) + (size_t)mwb * e.pitch_c;
+      e.c = __builtin_amdgcn_make_buffer_rsrc(cb, 0, rows * e.pitch_c, 0x00020000);
+      e.res = g.resid ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.resid)) + (size_t)mwb * e.pitch_c, 0,
+                                                          rows * e.pitch_c, 0x00020000)
+                      : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
+      e.aux = has_aux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(auxp)) + (size_t)mwb * e.pitch_aux, 0,
+                                                          rows * e.pitch_aux, 0x00020000)
+                      : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
+      e.vc = (unsigned)(lg * 4) * e.pitch_c + (unsigned)(nw + li * 4) * esz;
+      e.vaux = (unsigned)(lg * 4) * e.pitch_aux + (unsigned)(nw + li * 4) * 2u;
+      if (mode == 0) gemm8p_epilogue<0>(e, false, false, g.alpha, bias4, acc);
+      else if (mode == 1) gemm8p_epilogue<1>(e, has_aux, false, g.alpha, bias4, acc);
+      else if (mode == 2) gemm8p_epilogue<2>(e, true, false, g.alpha, bias4, acc);
+      else gemm8p_epilogue<3>(e, false, g.resid != nullptr, g.alpha, bias4, acc);
+    } else {
+      // (guarded epilogue of gemm.hip, dependent loads issued at their use: matrices of 4 GiB and more, rare activations)
 #pragma unroll
-  for (int ha = 0; ha < 2; ++ha) {
-    typename AuxPre<bf16>::V upre[4][4];     // one block's 16 rows are requested together (both blocks at once spill: 32 row addresses)
-    if (have_upre) {
-      const bf16* U = static_cast<const bf16*>(g.aux_in) + n0 + 64 * wc + li * 4;
+      for (int ha = 0; ha < 2; ++ha) {
+        typename AuxPre<bf16>::V upre[4][4];
+        const bool have_upre = false;
+        f32x4 blk[4][4];
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = min(m0 + 128 * ha + 64 * wr + i * 16 + lg * 4 + r, g.M - 1);
-          upre[i][r] = *reinterpret_cast<const bf16x4*>(U + (size_t)row * g.ldaux);
+        for (int i = 0; i < 4; ++i) {
+          blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
+          blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
         }
+        gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, have_upre);
+      }
     }
-    f32x4 blk[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
-      blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
-    }
-    gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, have_upre);
   }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
