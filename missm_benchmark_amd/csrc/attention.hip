@@ -453,6 +453,182 @@ __global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_bwd_mfm
 
 
 // ---------------------------------------------------------------------------------------------------
+// Single-pass backward (bf16, head_dim 64, 97 <= L <= 224, not causal).  The two-pass kernel above recomputes the scores and
+// dP twice (query-on-lane for dQ, key-on-lane for dK / dV): 2444 MFMAs, 2 x 169 score tiles of exp2 / VALU work and two LDS
+// stagings per (sequence, head).  Here ONE key-on-lane sweep feeds all three gradients:
+//   * 16 waves, one workgroup per CU; Q, dO and K sit in LDS (3 x 28 KiB), this wave's K / V fragments in registers;
+//   * wave kt < nt ("S-wave") owns key tile kt: per block of 32 queries it forms S^T and dP^T tiles (4 MFMAs), p = exp2(...),
+//     dS = p * dP', accumulates dV^T += dO^T P and dK^T += Q^T dS through C-as-operand fragments (8 MFMAs) exactly like
+//     pass B above - and drops its bf16 dS tile into a double-buffered LDS block [32 queries][224 keys];
+//   * the remaining 16 - nt waves ("dQ-waves") turn the PREVIOUS block's dS into dQ^T = K^T dS^T (8 output tiles x 7 key
+//     steps, A = transposed K reads, B = one ds_read_b128 of the dS block) while the S-waves are on the next block:
+//     one workgroup barrier per block, nothing is accumulated with atomics, dQ is written once.
+//   The dS block stores the keys of each 32-key group in the C-as-operand order (mma.h) so that the dQ-waves' B fragment
+//   matches TrFrag's k order with a single 16-byte read.
+// Per (sequence, head) at S = 197: 1796 MFMAs, 169 score tiles of VALU work, one staging.
+//
+// MEASURED SLOWER than the two-pass kernel and therefore OPT-IN (MISSM_ATTN_SP=1; parity-tested either way): 318 us against
+// 267 us at 256 frames x 12 heads.  Three 28 KiB operand tiles leave room for ONE workgroup per CU, so nothing hides a unit's
+// memory phase: with both compute stages switched off the kernel still takes 158 us (13.2 us per unit: 2.3 launch, the rest
+// the 179 KB a unit moves at an effective 3.6 TB/s - a head's slice is 128 bytes of every 4.6 KB QKV row), the stages add
+// 86 us (S-waves) + 81 us (dQ-waves) on top, and starting the CUs 2-6 us apart only added the delay.  The two-pass kernel
+// runs two workgroups per CU and overlaps one's staging with the other's MFMAs.  What would make this design pay: Q / dO
+// streamed per 32-query block (LDS 76 KB -> the next unit's K load under the last blocks), or a head-major QKV layout.
+// ---------------------------------------------------------------------------------------------------
+constexpr int SPW = 16;                    // waves of the single-pass workgroup
+constexpr int DSP = 464;                   // bytes per query row of the dS block (224 keys x 2 B, padded: 4 rows apart = +16 banks)
+
+template <int NTP>
+__global__ __launch_bounds__(SPW * 64) void attn_bwd_sp_kernel(AttnArgs a) {
+  using T = bf16;
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T);      // 128
+  constexpr int LP = NTP * 16;
+  constexpr int KSQ = HD / M_::KS;         // 2
+  constexpr int NU = NTP / 2;              // blocks of 32 queries / steps of 32 keys
+  static_assert(NTP % 2 == 0 && NTP <= SPW - 2 && LP * 2 <= DSP, "single-pass backward: tile count");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* XQ = smem;                         // Q   [LP][64]
+  char* XO = smem + LP * RBv;              // dO
+  char* XK = smem + 2 * LP * RBv;          // K
+  char* dsb = smem + 3 * LP * RBv;         // [2][32][DSP]
+  float* kbias = reinterpret_cast<float*>(dsb + 2 * 32 * DSP);
+  float* nlse = kbias + LP;                // -lse / scale (-inf past L): initial score accumulators
+  float* nD = nlse + LP;                   // -rowsum(dO . O): initial dP accumulators
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  const int unit = blockIdx.x;
+  const int seq = unit / a.H, h = unit % a.H;
+  const size_t base = seq_base(a, seq);
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const T* dout = static_cast<const T*>(a.dout);
+  const T* fout = static_cast<const T*>(a.out);
+  T* dqkv = static_cast<T*>(a.dqkv);
+  const int L = a.L;
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const float inv_scale = 1.0f / a.scale;
+  const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
+  const int nt = (L + 15) >> 4;            // key / query tiles that hold at least one row (host: nt <= NTP <= 14)
+
+  stage_head<T, RBv, SPW>(XQ, qkv, base, a.tok_stride, a.ld, h * HD, L, LP, lane, wave);
+  stage_head<T, RBv, SPW>(XO, dout, base, a.tok_stride, a.ldo, h * HD, L, LP, lane, wave);
+  stage_head<T, RBv, SPW>(XK, qkv, base, a.tok_stride, a.ld, a.d + h * HD, L, LP, lane, wave);
+  for (int k = tid; k < LP; k += SPW * 64) {
+    kbias[k] = (k < L && (!a.key_mask || a.key_mask[(size_t)seq * L + k] != 0)) ? 0.f : kNegInf;
+    nlse[k] = k < L ? -lse[k] * inv_scale : kNegInf;
+  }
+  for (int i = tid; i < 2 * 32 * DSP / 16; i += SPW * 64) reinterpret_cast<f32x4*>(dsb)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < NTP) {                        // D of query tile `wave` (dO . O over the head, 16 columns per lane, summed over lg)
+    const int qi = wave * 16 + li;
+    const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
+    float dsum = 0.f;
+    if (qi < L) {
+#pragma unroll
+      for (int ks = 0; ks < KSQ; ++ks)
+        dsum = frag_dot(*reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL),
+                        *reinterpret_cast<const Frag*>(fout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL), dsum);
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    if (lg == 0) nD[qi] = -dsum;
+  }
+  const bool s_wave = wave < nt;           // wave-uniform role
+  const int key = wave * 16 + li;          // (S-waves) this lane's key column
+  const bool kin = s_wave && key < L;
+  const size_t krow = base + (size_t)(kin ? key : 0) * a.tok_stride;
+  Frag kf[KSQ], vf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    kf[ks] = M_::zero(); vf[ks] = M_::zero();
+    if (kin) {
+      kf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+      vf[ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const float kb = s_wave ? kbias[key] : 0.f;
+  f32x4 dva[HD / 16], dka[HD / 16];        // (S-waves) dV^T / dK^T of the key tile
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) { dva[dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dka[dt] = dva[dt]; }
+  // dS block addressing.  Writer: query row c * 16 + 4 lg + r, key slot inside the 32-key group = 8 (li >> 2) + 4 (kt & 1) + (li & 3)
+  const int ds_wr = (4 * lg) * DSP + ((wave >> 1) * 32 + 8 * (li >> 2) + 4 * (wave & 1) + (li & 3)) * 2;
+  const int ndq = SPW - nt, dq_idx = wave - nt;   // (dQ-waves)
+
+  // Block qb: S-waves fill dS buffer qb & 1, barrier, dQ-waves consume it while the S-waves fill the other buffer for block
+  // qb + 1; the next barrier is passed only when the dQ-waves are done with buffer qb & 1, which the S-waves refill in qb + 2.
+#pragma unroll 1
+  for (int qb = 0; qb < NU; ++qb) {
+    if (2 * qb >= nt) break;               // (uniform) no query left
+    if (s_wave) {
+      char* buf = dsb + (qb & 1) * (32 * DSP);
+      f32x4 pv4[2], dsv[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        const int qt = 2 * qb + c;
+        if (qt >= nt) { pv4[c] = f32x4{0.f, 0.f, 0.f, 0.f}; dsv[c] = pv4[c]; continue; }   // (uniform) last block, odd tile count
+        f32x4 sc = *reinterpret_cast<const f32x4*>(nlse + qt * 16 + 4 * lg);
+        f32x4 dp = *reinterpret_cast<const f32x4*>(nD + qt * 16 + 4 * lg);
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks) {
+          const int off = swz<RBv>(qt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+          sc = M_::step(lds_frag<T>(XQ, off), kf[ks], sc);
+          dp = M_::step(lds_frag<T>(XO, off), vf[ks], dp);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kb);
+          pv4[c][r] = pv;
+          dsv[c][r] = pv * dp[r];
+        }
+      }
+      const Frag pf = M_::from_acc(pv4[0], pv4[1]);
+      const Frag dsf = M_::from_acc(dsv[0], dsv[1]);
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) *reinterpret_cast<T*>(buf + ds_wr + (c * 16 + r) * DSP) = dsf[4 * c + r];
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) {
+        dva[dt] = M_::step(TrFrag<T, RBv>::load(XO, qb * M_::KS, dt * 16, lane), pf, dva[dt]);
+        dka[dt] = M_::step(TrFrag<T, RBv>::load(XQ, qb * M_::KS, dt * 16, lane), dsf, dka[dt]);
+      }
+    }
+    __syncthreads();
+    if (!s_wave) {
+      const char* buf = dsb + (qb & 1) * (32 * DSP);
+      for (int t = dq_idx; t < 8; t += ndq) {          // output tile (query tile t >> 2 of the block, head slice t & 3)
+        const int qt = 2 * qb + (t >> 2), dt = t & 3;
+        if (qt >= nt) continue;
+        const char* brow = buf + ((t >> 2) * 16 + li) * DSP + lg * 16;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          if (2 * u >= nt) continue;                     // (uniform) no key in this step
+          acc = M_::step(TrFrag<T, RBv>::load(XK, u * M_::KS, dt * 16, lane), *reinterpret_cast<const Frag*>(brow + u * 64), acc);
+        }
+        acc *= a.scale;
+        const int qi = qt * 16 + li;
+        if (qi < L) store4(dqkv + (base + (size_t)qi * a.tok_stride) * a.ld + h * HD + dt * 16 + 4 * lg, acc);
+      }
+    }
+  }
+  if (s_wave) {
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      dka[dt] *= a.scale;
+      if (kin) {
+        store4(dqkv + krow * a.ld + a.d + h * HD + dt * 16 + 4 * lg, dka[dt]);
+        store4(dqkv + krow * a.ld + 2 * a.d + h * HD + dt * 16 + 4 * lg, dva[dt]);
+      }
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Small-sequence path (L <= 32, any head_dim <= 128 that is a multiple of 8): the video tower's temporal
 // attention (L = T = 8, B*197 sequences x 12 heads) and the tiny parity configs.  No MFMA: one wavefront
 // packs 64 / L (sequence, head) pairs, lane = (pair, query); operands sit in LDS as T, math in fp32.
@@ -681,6 +857,18 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
   }
   if (hd != HD || L > 256) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64 and L<=256)", L, hd); return MISSM_ERR_INVALID; }
   dim3 grid(a.nseq * a.H);
+  if constexpr (BWD && sizeof(T) == 2) {
+    // single-pass backward (attn_bwd_sp_kernel), opt-in: measured slower than the two-pass kernel (see its header)
+    static const int use_sp = getenv("MISSM_ATTN_SP") ? atoi(getenv("MISSM_ATTN_SP")) : 0;
+    if (use_sp && !a.causal && L > 96 && L <= 224) {
+      constexpr int NTP = 14;
+      const size_t shmem = (size_t)3 * NTP * 16 * HD * 2 + 2 * 32 * DSP + (size_t)3 * NTP * 16 * 4;
+      auto k = attn_bwd_sp_kernel<NTP>;
+      int rc = launch_dyn(k, grid, dim3(SPW * 64), shmem, s, "attn_bwd_sp"); if (rc) return rc;
+      hipLaunchKernelGGL(k, grid, dim3(SPW * 64), shmem, s, a);
+      return missm_check_launch("attn_bwd_sp");
+    }
+  }
   // forward specialisations: FULL when every key tile but the last two is full (L > 16 (NTP - 2): S = 197 / NTP 14, S = 77 / NTP 6),
   // MASK when a key_padding_mask (or causality, which always comes with one here) can hit any tile
   const bool mask = a.key_mask != nullptr || a.causal;

@@ -325,6 +325,12 @@ CASES = [  # name, nseq-structure
     dict(name="mfma_s77_causal", B=4, T=1, S=77, H=3, hd=64, temporal=False, causal=True, mask=True),
     dict(name="mfma_s50", B=2, T=1, S=50, H=1, hd=64, temporal=False, causal=False, mask=True),
     dict(name="mfma_s256", B=1, T=1, S=256, H=2, hd=64, temporal=False, causal=True, mask=False),
+    # shapes of the opt-in single-pass backward (bf16, 97 <= S <= 224; test_attention_single_pass_backward re-runs them with
+    # MISSM_ATTN_SP=1): key mask, 7 / 9 / 14 key tiles (9, 7 and 2 dQ-waves), two frames per sample
+    dict(name="sp_s197_mask", B=2, T=1, S=197, H=2, hd=64, temporal=False, causal=False, mask=True),
+    dict(name="sp_s100", B=2, T=1, S=100, H=1, hd=64, temporal=False, causal=False, mask=True),
+    dict(name="sp_s130_t2", B=1, T=2, S=130, H=2, hd=64, temporal=False, causal=False, mask=False),
+    dict(name="sp_s224", B=1, T=1, S=224, H=2, hd=64, temporal=False, causal=False, mask=False),
 ]
 
 
@@ -504,6 +510,21 @@ def test_adam_matches_torch(ops):
         opt.step()
         ops.adam_step(p, dev(g * 4.0), m, v, step, 1e-3, weight_decay=0.01, grad_scale=0.25)
     assert rel(p, ref.detach()) < 1e-6
+
+
+def test_attention_single_pass_backward():
+    """The opt-in single-pass attention backward (MISSM_ATTN_SP=1, read once per process) against the same torch reference: the
+    S = 197 and sp_* cases of test_attention_fwd_bwd in a child process with the knob set."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("MISSM_ATTN_SP") == "1":
+        pytest.skip("already inside the single-pass child run")
+    env = dict(os.environ, MISSM_ATTN_SP="1")
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-k",
+                          "test_attention_fwd_bwd and (sp_s or mfma_s197)"], capture_output=True, text=True, timeout=600, env=env,
+                         cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.returncode == 0 and " passed" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_library_loaded_before_torch_still_sees_the_gpu():
