@@ -87,6 +87,8 @@ __device__ __forceinline__ void gemm8p_prologue(char* lds, const Gemm8pSrc& src,
 // (rows past M: loads return 0, stores are dropped), so the block is straight-line code: all loads of a block are issued
 // before the first use, stores follow back to back.  A lane owns rows 4 lg + r of each 16-row tile i and 4 consecutive columns.
 // Row (ha, i, r) is a SCALAR offset (128 ha + 16 i + r) * row pitch; the lane offset is one VGPR per matrix.
+// (Non-temporal stores, aux = nt, were measured: +6..8 % on the two activation epilogues alone, -2 % on QKV, 465.9 vs 467.4
+//  samples/s for the whole step - the outputs are read back by the next kernel; kept at the default policy.)
 // ---------------------------------------------------------------------------------------------------------------------
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
