@@ -287,6 +287,23 @@ def main():
                      "frac": round(aby / (ams * 1e-3) / 1e9 / 8000.0, 4), "traffic": None,
                      "mfma_TFLOP_per_s": round(afl / (ams * 1e-3) / 1e12, 1), "mfma_frac": round(afl / (ams * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                      "launches": len(aprof), "attention_ms_per_step": round(ams / 2, 2)}
+    if roof_attn is not None and prof:
+        # the north star words the attention block as "QKV projection + softmax.V": the fused-QKV projection GEMMs (N = 3K forward,
+        # K = 3N / M = 3N for its dX / dW) and the attention kernels TOGETHER, flops over the sum of their launch times.  The QKV
+        # projection stays a separate GEMM launch (training must write qkv for the backward either way - DESIGN 4.2).
+        is_qkv_f = lambda sh: sh[3] == 0 and sh[4] == 0 and sh[1] == 3 * sh[2]          # noqa: E731  [rows, 3d, d]
+        is_qkv_b = lambda sh: (sh[3] == 0 and sh[4] == 0 and sh[2] == 3 * sh[1]) or (sh[3] == 1 and sh[0] == 3 * sh[1])   # noqa: E731
+        qf = [(p[0].elapsed_time(p[1]), p[2]) for p in prof if is_qkv_f(p[3])]
+        qb = [(p[0].elapsed_time(p[1]), p[2]) for p in prof if is_qkv_b(p[3])]
+        af = [(p[0].elapsed_time(p[1]), p[2]) for p in aprof if p[4] == "fwd"]
+        ab = [(p[0].elapsed_time(p[1]), p[2]) for p in aprof if p[4] == "bwd"]
+        tf = lambda items: sum(f for _, f in items) / (sum(t for t, _ in items) * 1e-3) / 1e12 if items else 0.0   # noqa: E731
+        roof_attn["qkv_projection_plus_attention"] = {
+            "forward_TFLOP_per_s": round(tf(qf + af), 1), "forward_mfma_frac": round(tf(qf + af) / PEAK_BF16_TFLOPS, 4),
+            "forward_backward_TFLOP_per_s": round(tf(qf + af + qb + ab), 1),
+            "forward_backward_mfma_frac": round(tf(qf + af + qb + ab) / PEAK_BF16_TFLOPS, 4),
+            "qkv_gemm_forward_TFLOP_per_s": round(tf(qf), 1), "attention_forward_TFLOP_per_s": round(tf(af), 1),
+            "attention_backward_TFLOP_per_s": round(tf(ab), 1)}
     roof = None
     if prof:
         flops = sum(p[2] for p in prof)

@@ -962,11 +962,25 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
   if (use8p_tn && dtype == kBF16 && trans_a && trans_b && out_f32 && !resid && act == MISSM_ACT_NONE && !bias && M % 128 == 0 &&
       N % 128 == 0 && K >= tn_min_k && (K >= 20000 || ((M + 255) / 256) * ((N + 255) / 256) * (ngroups > 1 ? ngroups : 1) >= 18) && (size_t)K * lda * 2 < (size_t(1) << 32) && (size_t)K * ldb * 2 < (size_t(1) << 32)) {
     const int tm2 = (M + 255) / 256, tn2 = (N + 255) / 256, t2 = tm2 * tn2;
-    int sp = 256 / (t2 * g.ngroups);
-    if (sp < 1) sp = 1;
-    int kps8 = ((K + sp - 1) / sp + 127) / 128 * 128;
-    if (kps8 < 1024) kps8 = 1024;
-    sp = (K + kps8 - 1) / kps8;
+    // K slices: minimise  rounds of 256 workgroups x (K tiles per slice x ~1.4 us + ~9 us of prologue / park)  + the reduce.
+    // One slice per 256 / tiles is the optimum when it fills a round exactly (video tower: 27 tiles x 9 slices), but four grouped
+    // [3072 x 768] gradients are 144 tiles: one slice leaves 44 % of the CUs idle for the whole reduction, three slices are two
+    // full rounds of a third of the length.
+    int sp = 1, kps8 = (K + 127) / 128 * 128;
+    {
+      const int wgs1 = t2 * g.ngroups;
+      float best = 1e30f;
+      for (int c = 1; c <= 64; ++c) {
+        int kc = ((K + c - 1) / c + 127) / 128 * 128;
+        if (kc < 1024) kc = 1024;
+        const int cs = (K + kc - 1) / kc;                 // slices actually needed at this slice length
+        if (cs != c && c > 1) continue;
+        const int rounds = (wgs1 * cs + 255) / 256;
+        // (the reduce re-reads one 256 KiB fp32 tile per workgroup: ~0.055 us each at 5 TB/s)
+        const float cost = rounds * ((kc / 64) * 1.4f + 9.0f) + (cs > 1 ? 3.0f + 0.055f * (wgs1 * cs) : 0.0f);
+        if (cost < best) { best = cost; sp = cs; kps8 = kc; }
+      }
+    }
     g.tiles_m = tm2; g.tiles_n = tn2; g.splitk = sp; g.k_per_split = kps8;
     g.group_m = group_m_env > 0 ? group_m_env : (tn2 >= 4 ? 8 : 1);
     if (splitk_workspace(stream, (size_t)g.ngroups * sp * t2 * (256 * 256 * sizeof(float)), &g.ws)) {
