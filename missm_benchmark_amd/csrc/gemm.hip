@@ -638,6 +638,7 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
 
 }  // namespace missm
 #include "gemm8p.h"
+#include "gemm4w.h"
 namespace missm {
 
 // Measured and removed again (git history has them; all correct, none faster on the hot-path shapes):
@@ -1002,6 +1003,37 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
     return missm_check_launch("gemm8p_tn");
   }
   if (ngroups > 1 && (trans_a || trans_b)) return MISSM_GROUPED_UNAVAILABLE;
+  // ---- 256x128 tile, 4 waves, two workgroups per CU (gemm4w.h) - OPT-IN.  Measured inside the step against the 8-phase kernel
+  // (profiles/r02_gemm_insitu_8p_vs_4w.txt, one stream): it wins where the 256x256 grid leaves partial rounds or the epilogue
+  // weighs most - every grouped launch of the four 197-token towers (N = 768: -8..-18 %, N = 2304 / 3072: 0..-6 %) and the video
+  // tower's out-projection shapes (N = 768, K = 768: -7..-10 %); it ties on the K = 768 / N >= 2304 video shapes and loses 2-4 %
+  // at K = 2304 / 3072 (8 % at 4096^3), where the main loop dominates and the big tile halves the L2 -> LDS bytes per flop.
+  // That rule (MISSM_GEMM_4W=3) takes 1.2 ms out of the 52 ms of serial GEMM time - and makes the real two-stream step 0.75 %
+  // SLOWER (461.9 vs 465.2 samples/s, three alternating runs on one box): what it gains alone - filled partial rounds, hidden
+  // epilogues - the second stream already provides, and 80 KiB workgroups of one lane fragment the CUs that the other lane's
+  // 128 KiB workgroups need whole.  Default therefore 0.  MISSM_GEMM_4W: 0 never, 1 wherever legal, 2 whenever K <= 1024,
+  // 3 the single-stream rule.
+  static const int use4w = getenv("MISSM_GEMM_4W") ? atoi(getenv("MISSM_GEMM_4W")) : 0;
+  const bool rule4w = use4w == 1 || (use4w == 2 && K <= 1024) || (use4w == 3 && (ngroups > 1 || (K <= 1024 && N <= 1024)));
+  if (rule4w && dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && K % 64 == 0 && K >= 128 &&
+      (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU) &&
+      (size_t)lda * 2 * 128 < (size_t(1) << 31) && (size_t)ldb * 2 * 128 < (size_t(1) << 31) &&
+      ((M + 255) / 256) * ((N + 127) / 128) * g.ngroups >= 256) {
+    g.group_tiles_m = (M + 255) / 256;
+    g.tiles_m = g.group_tiles_m * g.ngroups; g.tiles_n = (N + 127) / 128;
+    g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 8 ? 8 : 1);
+    static bool attr4 = false;
+    if (!attr4) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4w_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+        missm_set_error("gemm: cannot raise dynamic LDS to 80 KiB");
+        return MISSM_ERR_LAUNCH;
+      }
+      attr4 = true;
+    }
+    log_shape(M);
+    hipLaunchKernelGGL(gemm4w_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 80 * 1024, s, g);
+    return missm_check_launch("gemm4w");
+  }
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
   // ---- 256x256 tile (16 waves, one workgroup per CU) for long-M NT products whose tile grid fills whole rounds of 256 CUs
   if (dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && big_env != 0 &&

@@ -198,6 +198,40 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
 #undef MISSM_SA
 }
 
+// The wave's 128 x 64 outputs (rows mwb + 128 ha + 16 i + 4 lg + r, columns nw + 4 li ..+3) through the branch-free epilogue;
+// false if the case is not covered (the caller takes the guarded epilogue of gemm.hip): buffer offsets are 32-bit, so matrices of
+// 4 GiB and more, ragged column blocks, accumulate and the rare activations stay there.
+__device__ __forceinline__ bool gemm8p_store_tile(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], int mwb, int nw, int lane,
+                                                  f32x4 bias4) {
+  const int li = lane & 15, lg = lane >> 4;
+  const int esz = g.out_f32 ? 4 : 2;
+  const int mode = g.out_f32 ? (g.act == MISSM_ACT_NONE ? 3 : -1)
+                             : (g.act == MISSM_ACT_NONE ? 0 : (g.act == MISSM_ACT_QGELU ? 1 : (g.act == MISSM_ACT_DQGELU ? 2 : -1)));
+  const void* auxp = mode == 1 ? g.aux_out : (mode == 2 ? g.aux_in : nullptr);
+  const bool has_aux = auxp != nullptr;
+  const bool fast = mode >= 0 && g.vec_ok && !g.accumulate && nw + 64 <= g.N && (mode != 2 || has_aux) && (mode == 3 || !g.resid) &&
+                    (size_t)g.M * g.ldc * esz < (size_t(1) << 32) && (size_t)g.M * g.ldaux * 2 < (size_t(1) << 32);
+  if (!fast) return false;
+  Epi8p e;
+  e.pitch_c = (unsigned)g.ldc * esz; e.pitch_aux = (unsigned)g.ldaux * 2u;
+  const unsigned rows = (unsigned)min(max(g.M - mwb, 0), 192);
+  char* cb = static_cast<char*>(g.C) + (size_t)mwb * e.pitch_c;
+  e.c = __builtin_amdgcn_make_buffer_rsrc(cb, 0, rows * e.pitch_c, 0x00020000);
+  e.res = g.resid ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.resid)) + (size_t)mwb * e.pitch_c, 0,
+                                                      rows * e.pitch_c, 0x00020000)
+                  : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
+  e.aux = has_aux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(auxp)) + (size_t)mwb * e.pitch_aux, 0,
+                                                      rows * e.pitch_aux, 0x00020000)
+                  : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
+  e.vc = (unsigned)(lg * 4) * e.pitch_c + (unsigned)(nw + li * 4) * esz;
+  e.vaux = (unsigned)(lg * 4) * e.pitch_aux + (unsigned)(nw + li * 4) * 2u;
+  if (mode == 0) gemm8p_epilogue<0>(e, false, false, g.alpha, bias4, acc);
+  else if (mode == 1) gemm8p_epilogue<1>(e, has_aux, false, g.alpha, bias4, acc);
+  else if (mode == 2) gemm8p_epilogue<2>(e, true, false, g.alpha, bias4, acc);
+  else gemm8p_epilogue<3>(e, false, g.resid != nullptr, g.alpha, bias4, acc);
+  return true;
+}
+
 // STAGGER: waves 4-7 run one barrier behind waves 0-3.
 // The grid is PERSISTENT (one workgroup per CU walks tiles bid, bid + gridDim.x, ...): once a tile's main loop has ended every
 // LDS slot is free, so the next tile's first seven half tiles are requested BEFORE this tile's epilogue - their 1.5-2.4 us of
@@ -366,48 +400,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
 
   // ---- epilogue: two 64 x 64 blocks per wave (A half 0 / 1), a lane owns rows 4 lg + r of each 16-row tile and the four
   // consecutive columns 64 wc + 4 li + {0, 1 (B half 0), 2, 3 (B half 1)}: the same register picture as gemm_kernel's.
-  {
-    const int mwb = m0 + 64 * wr, nw = n0 + 64 * wc;
-    const int esz = g.out_f32 ? 4 : 2;
-    const int mode = g.out_f32 ? (g.act == MISSM_ACT_NONE ? 3 : -1)
-                               : (g.act == MISSM_ACT_NONE ? 0 : (g.act == MISSM_ACT_QGELU ? 1 : (g.act == MISSM_ACT_DQGELU ? 2 : -1)));
-    const void* auxp = mode == 1 ? g.aux_out : (mode == 2 ? g.aux_in : nullptr);
-    const bool has_aux = auxp != nullptr;
-    // (buffer offsets are 32-bit: matrices of 4 GiB and more keep the guarded epilogue)
-    const bool fast = mode >= 0 && g.vec_ok && !g.accumulate && nw + 64 <= g.N && (mode != 2 || has_aux) && (mode == 3 || !g.resid) &&
-                      (size_t)g.M * g.ldc * esz < (size_t(1) << 32) && (size_t)g.M * g.ldaux * 2 < (size_t(1) << 32);
-    if (fast) {
-      Epi8p e;
-      e.pitch_c = (unsigned)g.ldc * esz; e.pitch_aux = (unsigned)g.ldaux * 2u;
-      const unsigned rows = (unsigned)min(max(g.M - mwb, 0), 192);
-      char* cb = static_cast<char*>(g.C) + (size_t)mwb * e.pitch_c;
-      e.c = __builtin_amdgcn_make_buffer_rsrc(cb, 0, rows * e.pitch_c, 0x00020000);
-      e.res = g.resid ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.resid)) + (size_t)mwb * e.pitch_c, 0,
-                                                          rows * e.pitch_c, 0x00020000)
-                      : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
-      e.aux = has_aux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(auxp)) + (size_t)mwb * e.pitch_aux, 0,
-                                                          rows * e.pitch_aux, 0x00020000)
-                      : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
-      e.vc = (unsigned)(lg * 4) * e.pitch_c + (unsigned)(nw + li * 4) * esz;
-      e.vaux = (unsigned)(lg * 4) * e.pitch_aux + (unsigned)(nw + li * 4) * 2u;
-      if (mode == 0) gemm8p_epilogue<0>(e, false, false, g.alpha, bias4, acc);
-      else if (mode == 1) gemm8p_epilogue<1>(e, has_aux, false, g.alpha, bias4, acc);
-      else if (mode == 2) gemm8p_epilogue<2>(e, true, false, g.alpha, bias4, acc);
-      else gemm8p_epilogue<3>(e, false, g.resid != nullptr, g.alpha, bias4, acc);
-    } else {
-      // (guarded epilogue of gemm.hip, dependent loads issued at their use: matrices of 4 GiB and more, rare activations)
+  if (!gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4)) {
+    // (guarded epilogue of gemm.hip, dependent loads issued at their use: matrices of 4 GiB and more, rare activations)
 #pragma unroll
-      for (int ha = 0; ha < 2; ++ha) {
-        typename AuxPre<bf16>::V upre[4][4];
-        const bool have_upre = false;
-        f32x4 blk[4][4];
+    for (int ha = 0; ha < 2; ++ha) {
+      typename AuxPre<bf16>::V upre[4][4];
+      f32x4 blk[4][4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
-          blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
-        }
-        gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, have_upre);
+      for (int i = 0; i < 4; ++i) {
+        blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
+        blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
       }
+      gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, false);
     }
   }
   if (g.dbg && tid == 0) {

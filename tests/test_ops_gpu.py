@@ -46,7 +46,8 @@ def q(t, dtype):
 
 # ------------------------------------------------------------------ GEMM
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 5, 256), (64, 2304, 64), (4096, 1536, 2048)])
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (300, 200, 192), (1000, 768, 768), (37, 5, 256), (64, 2304, 64), (4096, 1536, 2048),
+                                   (16200, 768, 256)])   # (64 x 6 tiles of 256 x 128 with ragged rows)
 def test_gemm_bias(ops, dtype, M, N, K):
     a, b, bias = q(rnd(M, K, seed=1), dtype), q(rnd(N, K, seed=2), dtype), rnd(N, seed=3)
     out = torch.empty(M, N, device="cuda", dtype=dtype)
@@ -510,6 +511,20 @@ def test_adam_matches_torch(ops):
         opt.step()
         ops.adam_step(p, dev(g * 4.0), m, v, step, 1e-3, weight_decay=0.01, grad_scale=0.25)
     assert rel(p, ref.detach()) < 1e-6
+
+
+def test_gemm_tile_kernels_on_the_step_shapes():
+    """Every NT epilogue (bias -> bf16, + fp32 residual, QuickGELU + saved pre-activation, dQuickGELU) on the training step's shapes,
+    once with the default kernel choice and once with the opt-in 256 x 128 two-workgroups-per-CU kernel wherever it is legal
+    (MISSM_GEMM_4W=1, read once per process): tools/gemm_nt_ab.py checks each against fp32 torch."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for knob in ("0", "1"):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_nt_ab.py")], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, MISSM_GEMM_4W=knob), cwd=root)
+        assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_attention_single_pass_backward():

@@ -7,7 +7,7 @@ rows = []
 with open(sys.argv[2]) as f:
     for r in csv.DictReader(f):
         n = r["Kernel_Name"]
-        if ("gemm8p_kernel" in n or "gemm8p_tn_kernel" in n or "gemm_kernel" in n) and "splitk" not in n:
+        if ("gemm8p_kernel" in n or "gemm8p_tn_kernel" in n or "gemm_kernel" in n or "gemm4w_kernel" in n) and "splitk" not in n:
             rows.append((int(r["Dispatch_Id"]), n, int(r["End_Timestamp"]) - int(r["Start_Timestamp"])))
 rows.sort()
 assert len(rows) == len(log), (len(rows), len(log))
@@ -15,7 +15,7 @@ agg = collections.defaultdict(lambda: [0, 0.0, ""])
 for (disp, name, ns), sh in zip(rows, log):
     a = agg[sh]
     a[0] += 1; a[1] += ns
-    a[2] = "8p" if "gemm8p_kernel" in name else ("8p_tn" if "gemm8p_tn" in name else "128")
+    a[2] = "8p" if "gemm8p_kernel" in name else ("8p_tn" if "gemm8p_tn" in name else ("4w" if "gemm4w" in name else "128"))
 tot = sum(a[1] for a in agg.values())
 print(f"{'M':>6} {'N':>5} {'K':>6} ta tb act f32 res ain aout cs acc grp kern   calls   avg_us  TFLOP/s  ms/step  share")
 for sh, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
