@@ -30,6 +30,7 @@ import contextlib
 
 _null = contextlib.nullcontext
 _FUSED_UPDATE = os.environ.get("MISSM_FUSED_ADAM", "1") != "0"   # A/B switch: Adam fused with the weight-shadow refresh
+_BUCKET_UPDATE = os.environ.get("MISSM_BUCKET_ADAM", "1") != "0"  # A/B switch: eager mode updates bucket by bucket (else tower by tower)
 
 
 class FlatGroup:
@@ -59,6 +60,11 @@ class FlatGroup:
                 if p.grad is not None:
                     g.copy_(p.grad)
                 p.grad = g
+
+
+def _covers(done, tower) -> bool:
+    """the ranges updated during the backward are exactly the tower's layer buckets (everything but its tail range)"""
+    return sorted(done) == sorted(tower.bucket_ranges()[:-1])
 
 
 class TrainEngine:
@@ -100,9 +106,14 @@ class TrainEngine:
         self._eager_done = set()
         self._host_sync_before_collective = dist.is_initialized() and dist.get_backend(process_group) == "gloo"
         self.comm_stream = torch.cuda.Stream() if (self.world > 1 and torch.cuda.is_available()) else None
+        # eager mode updates a tower bucket by bucket (three layers' weight matrices at a time, as their gradients become final)
+        # on a side stream: on one GPU a stream of its own, on N GPUs the communication stream, behind the bucket's all-reduce -
+        # only the last bucket's update is left behind the backward instead of the whole tower's (0.7 ms for the video tower)
+        self.update_stream = (self.comm_stream if self.world > 1 else torch.cuda.Stream()) if (eager_step and torch.cuda.is_available()) else None
+        self._bucket_updated = {}            # id(tower) -> [flat ranges already updated during this backward]
         for t in self.towers:
             t._post_backward = self._tower_done if (self.world > 1 or eager_step) else None
-            t._bucket_hook = self._bucket_ready if self.overlap else None
+            t._bucket_hook = self._bucket_ready if (self.overlap or eager_step) else None
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -138,9 +149,28 @@ class TrainEngine:
     def _bucket_ready(self, tower: ClipTower, lo: int, hi: int):
         """called from inside a tower's backward: flat range [lo, hi) of its gradient is final (reverse execution order, like
         DDP's buckets - train_ddp.py:188-189,253 - but as a few 85-115 MB messages: xGMI rings are per-link bound)"""
-        if tower._accumulate:
-            raise RuntimeError("TrainEngine(overlap=True): accumulating backward (see _tower_done)")
-        self._all_reduce_async(tower.flat_grad()[lo:hi])
+        if self.world > 1 and self.overlap:
+            if tower._accumulate:
+                raise RuntimeError("TrainEngine(overlap=True): accumulating backward (see _tower_done)")
+            self._all_reduce_async(tower.flat_grad()[lo:hi])
+        elif self.world > 1:
+            return                                # overlap=False: everything is reduced in reduce_gradients()
+        if not (_FUSED_UPDATE and _BUCKET_UPDATE and self.eager_step and tower.flat_master().is_cuda and tower.fused_update_ready()) or tower._accumulate:
+            return                                # (an accumulating second backward is refused in _tower_done)
+        if id(tower) in self._eager_done:
+            return                                # second backward before step(): _tower_done raises
+        # the bucket's update: behind its reduction on the communication stream (N GPUs) / behind the kernels that produced it
+        # on the update stream (1 GPU).  The layers below never read these weights again in this backward.
+        hs = []
+        if self.world > 1:
+            hs, self._pending = self._pending, []
+        else:
+            self.update_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.update_stream):
+            for h in hs:
+                h.wait()
+            self._adam_on(tower.flat_master(), tower.flat_grad(), tower, flat_range=(lo, hi))
+        self._bucket_updated.setdefault(id(tower), []).append((lo, hi))
 
     def _tower_done(self, tower: ClipTower):
         """called by the tower's backward on the stream it ran on, after its last kernel was enqueued"""
@@ -152,6 +182,10 @@ class TrainEngine:
             raise RuntimeError("TrainEngine(overlap=True) all-reduces a tower's gradient right behind its backward: a second, "
                                "accumulating backward before step() would be reduced twice.  Use overlap=False for gradient "
                                "accumulation.")
+        done = self._bucket_updated.pop(id(tower), [])
+        rest = None if not done else (tower.tail_range() if _covers(done, tower) else "mixed")
+        if rest == "mixed":
+            raise RuntimeError("TrainEngine: a tower's buckets were updated only in part during its backward")
         if self.world > 1:
             if not self.overlap:
                 return
@@ -163,12 +197,17 @@ class TrainEngine:
                 hs, self._pending = self._pending, []
                 with torch.cuda.stream(self.comm_stream) if self.comm_stream is not None else _null():
                     for h in hs:
-                        h.wait()                  # comm stream waits for the reductions, then updates this tower
-                    self._adam_on(tower.flat_master(), tower.flat_grad(), tower)
+                        h.wait()                  # comm stream waits for the reductions, then updates (the rest of) this tower
+                    self._adam_on(tower.flat_master(), tower.flat_grad(), tower, flat_range=rest)
                     tower._ensure_ready()
                 self._eager_done.add(id(tower))
         elif self.eager_step and tower.flat_master().is_cuda:
-            self._adam_on(tower.flat_master(), tower.flat_grad(), tower)
+            if rest is None:
+                self._adam_on(tower.flat_master(), tower.flat_grad(), tower)
+            else:
+                self.update_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(self.update_stream):
+                    self._adam_on(tower.flat_master(), tower.flat_grad(), tower, flat_range=rest)
             tower._ensure_ready()                 # re-derive the compute-dtype weight copies behind the update
             self._eager_done.add(id(tower))
 
@@ -198,8 +237,10 @@ class TrainEngine:
                 torch.cuda.current_stream().wait_stream(self.comm_stream)
         elif self.rest is not None:
             self.rest.reattach()
+        if self.world == 1 and self.update_stream is not None:
+            torch.cuda.current_stream().wait_stream(self.update_stream)   # the towers' bucket-wise updates
 
-    def _adam_on(self, master, grad, t):
+    def _adam_on(self, master, grad, t, flat_range=None):
         if not master.is_cuda:
             raise RuntimeError("TrainEngine.apply_adam: parameters are not on a GPU (no CPU optimizer path)")
         key = master.data_ptr()
@@ -207,6 +248,16 @@ class TrainEngine:
             self._state[key] = (torch.zeros_like(master), torch.zeros_like(master))
         m, v = self._state[key]
         hp = (self.step_count + 1, self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
+        if flat_range is not None:
+            # one gradient bucket of a tower: the weight matrices that start inside it, and - if it is the tail range (it ends
+            # with the flat buffer) - the vector parameters behind the matrices
+            lo, hi = flat_range
+            t.adam_and_refresh(grad, m, v, *hp, grad_scale=1.0 / self.world, flat_range=flat_range)
+            vs = max(lo, t.vec_start())
+            if hi == master.numel() and vs < hi:
+                ops.adam_step(master[vs:], grad[vs:], m[vs:], v[vs:], *hp, grad_scale=1.0 / self.world)
+                t._grad_fresh = False
+            return
         if _FUSED_UPDATE and t is not None and t.fused_update_ready():
             # weight matrices: Adam fused with the refresh of their compute-dtype copies (one pass over p, g, m, v);
             # everything else (biases, LayerNorm, embeddings: the tail of the flat buffer): the plain fused Adam

@@ -457,13 +457,18 @@ def dropout_bwd(dy, mask, dx, p):
     return dx
 
 
-def adam_cast_batched(table, ntiles, master, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale, dtype_code):
+def adam_cast_batched(table, ntiles, master, g, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale, dtype_code, tile_start=0):
     """Adam on the weight matrices of a cast-tile table + refresh of their compute-dtype copies; g, m, v are flat buffers
-    parallel to ``master`` (same element offsets)."""
+    parallel to ``master`` (same element offsets).  ``tile_start`` / ``ntiles`` select a sub-range of the table (one gradient
+    bucket's matrices)."""
     if not (g.numel() == m.numel() == v.numel() == master.numel()) or g.dtype != torch.float32:
         raise _lib.MissmError("adam_cast_batched: g, m, v must be fp32 buffers parallel to the master buffer")
     off = lambda t: (t.data_ptr() - master.data_ptr()) // 4   # noqa: E731
-    _lib.call("missm_adam_cast_batched", table.data_ptr(), ntiles, off(g), off(m), off(v), int(step), float(lr), float(beta1),
+    if ntiles <= 0:
+        return
+    if tile_start < 0 or (tile_start + ntiles) * 40 > table.numel():
+        raise _lib.MissmError("adam_cast_batched: tile range outside the table")
+    _lib.call("missm_adam_cast_batched", table.data_ptr() + 40 * tile_start, ntiles, off(g), off(m), off(v), int(step), float(lr), float(beta1),
               float(beta2), float(eps), float(weight_decay), float(grad_scale), dtype_code, _s())
 
 

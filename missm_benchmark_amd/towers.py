@@ -248,6 +248,7 @@ class ClipTower(nn.Module):
         T = self.compute_dtype
         if not self._shadow:
             entries = []
+            self._cast_tile_range = []          # (flat offset of the block, first tile, tile count) in table order
             for key, b in self._mat_blocks.items():
                 n_out = sum(s[0] for _, s in b.items)
                 k_in = b.numel // n_out
@@ -255,6 +256,9 @@ class ClipTower(nn.Module):
                 w = src if T == torch.float32 else torch.empty(n_out, k_in, device=src.device, dtype=T)
                 wt = torch.empty(k_in, n_out, device=src.device, dtype=T)
                 self._shadow[key] = (w, wt)
+                ntile = ((n_out + 63) // 64) * ((k_in + 63) // 64)
+                first = self._cast_tile_range[-1][1] + self._cast_tile_range[-1][2] if self._cast_tile_range else 0
+                self._cast_tile_range.append((b.offset, first, ntile))
                 entries.append((src, None if T == torch.float32 else w, wt))
             self._cast_table, self._cast_tiles = ops.build_cast_table(entries, st.master.device)
         ops.cast_weights_batched(self._cast_table, self._cast_tiles, ops.F32 if T == torch.float32 else ops.BF16)
@@ -269,11 +273,19 @@ class ClipTower(nn.Module):
         st = self._store
         return bool(self._shadow) and st.master.is_cuda and self._shadow_version == self._version_key()
 
-    def adam_and_refresh(self, grad, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0):
+    def adam_and_refresh(self, grad, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, flat_range=None):
+        """``flat_range`` = (lo, hi): only the weight matrices whose blocks start inside that range of the flat buffer (one
+        gradient bucket, `layer_mat_range` / `tail_range`)"""
         st = self._store
         T = self.compute_dtype
-        ops.adam_cast_batched(self._cast_table, self._cast_tiles, st.master, grad, m, v, step, lr, beta1, beta2, eps, weight_decay,
-                              grad_scale, ops.F32 if T == torch.float32 else ops.BF16)
+        first, count = 0, self._cast_tiles
+        if flat_range is not None:
+            sel = [(f, n) for off, f, n in self._cast_tile_range if flat_range[0] <= off < flat_range[1]]
+            first, count = (sel[0][0], sum(n for _, n in sel)) if sel else (0, 0)
+            if sel and sel[-1][0] + sel[-1][1] - sel[0][0] != count:
+                raise RuntimeError("adam_and_refresh: the blocks of a flat range are not contiguous in the tile table")
+        ops.adam_cast_batched(self._cast_table, count, st.master, grad, m, v, step, lr, beta1, beta2, eps, weight_decay,
+                              grad_scale, ops.F32 if T == torch.float32 else ops.BF16, tile_start=first)
         # (the kernels write through raw pointers: the master's version counter, hence the shadows' validity, is unchanged)
 
     def _ensure_ready(self):
@@ -705,6 +717,17 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
         ops.token_embed_bwd(s.ids, dh[0], st.gview("embeddings.token_embedding.weight"), st.gview("embeddings.position_embedding.weight"), B, S, d)
 
 
+def _anchor_grad(*incoming):
+    """A real (zero) gradient for the anchor leaf.  The towers write their parameter gradients straight into the flat buffers on
+    the stream their forward ran on - autograd sees no AccumulateGrad for them, and it only joins the caller's stream with the
+    streams of LEAF accumulations when ``backward()`` ends.  With the anchor's accumulation on this stream the join covers every
+    kernel enqueued above: ``p.grad`` is safe to read (or to hand to ``torch.optim``) on the caller's stream as soon as
+    ``loss.backward()`` returns, as in the reference.  (Returning None here left that to chance: a gradient read right after
+    ``backward()`` raced with the last layers' kernels of the tower that ran alone on its stream.)"""
+    ref = next((g for g in incoming if torch.is_tensor(g)), None)
+    return torch.zeros((), device=ref.device if ref is not None else None)
+
+
 class _TowerFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, tower: ClipTower, inputs, need_grad, *params):
@@ -725,9 +748,9 @@ class _TowerFn(torch.autograd.Function):
         if ctx.nparams:
             st = tower._store
             grads = tuple(st.gview(n).clone() for n in tower._param_names)
-            return (None, None, None, None) + grads
+            return (_anchor_grad(d_last, d_pooled), None, None, None) + grads
         tower.attach_grads()
-        return (None, None, None, None)
+        return (_anchor_grad(d_last, d_pooled), None, None, None)
 
 
 class _TowerGroupFn(torch.autograd.Function):
@@ -754,7 +777,7 @@ class _TowerGroupFn(torch.autograd.Function):
             if t._post_backward is not None:
                 t._post_backward(t)
             t.attach_grads()
-        return (None, None, None, None)
+        return (_anchor_grad(*grads), None, None, None)
 
 
 def run_towers(towers, kwargs_list):

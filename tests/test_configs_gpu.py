@@ -326,6 +326,31 @@ def test_eager_engine_rejects_second_backward(pkg):
     eng.step()
 
 
+def test_gradients_are_final_when_backward_returns(pkg):
+    """``p.grad`` read on the caller's stream right after ``loss.backward()`` (no synchronize) is what it is after a device
+    synchronize: the towers write their gradients on their own streams, and ``backward()`` must end with the caller's stream
+    joined to them (a tower that runs alone on its stream used to race with such a read)."""
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    mods = ["image", "audio", "depth"]
+    T = pkg.towers.TowerConfig
+    enc = pkg.lb.LanguageBind({m: f"LanguageBind_{m.capitalize()}" for m in mods}, configs={m: T(kind="vision") for m in mods},
+                              compute_dtype=torch.bfloat16, seed=5)
+    args = types.SimpleNamespace(modality_types=mods, feature_dims=768, fusion_dim=256, dropout_prob=0.0, fusion_type="sum")
+    model = pkg.base.finetune_model(args, 8, enc).cuda()
+    g = torch.Generator().manual_seed(4)
+    data = _to_gpu({m: {"pixel_values": torch.randn(16, 3, 224, 224, generator=g)} for m in mods})
+    labels, missing = torch.randint(0, 8, (16,), generator=g).cuda(), torch.zeros(16, dtype=torch.int64).cuda()
+    for grouped in (False, True):
+        enc.group_towers = grouped
+        model.zero_grad(set_to_none=True)
+        HipCrossEntropyLoss()(model(data, missing), labels).backward()
+        early = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        torch.cuda.synchronize()
+        for k, p in model.named_parameters():
+            if p.grad is not None:
+                assert torch.equal(early[k], p.grad), (grouped, k)
+
+
 def test_lockstep_tower_groups_equal_separate_towers(pkg):
     """image / audio / depth towers (one config, one input shape) run in lock-step with grouped GEMM launches (one tile grid for
     the three of them, forward, dX and dW); the result must be what the towers give one after the other - and what the oracle
