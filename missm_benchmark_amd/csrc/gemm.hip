@@ -876,6 +876,9 @@ extern "C" void missm_gemm_release_workspaces(void) {
 // ngroups > 1: `groups` holds the operands of `ngroups` problems of this one shape (A .. colsum_a above are group 0's).  Returns
 // MISSM_GROUPED_UNAVAILABLE (without launching anything) when no grouped kernel covers the call: the caller loops instead.
 #define MISSM_GROUPED_UNAVAILABLE 1000
+// set around the row-remainder launch of a split NT product (see the 256x256 dispatch): that piece may take the 256x128 kernel
+static thread_local int g_row_remainder = 0;
+
 static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K, int lda, int ldb, int ldc, int trans_a,
                      int trans_b, float alpha, const float* bias, const float* resid, const void* aux_in, void* aux_out,
                      int ldaux, int act, int out_f32, int accumulate, int splitk, float* colsum_a, int dtype, void* stream,
@@ -1014,11 +1017,15 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
   // 128 KiB workgroups need whole.  Default therefore 0.  MISSM_GEMM_4W: 0 never, 1 wherever legal, 2 whenever K <= 1024,
   // 3 the single-stream rule.
   static const int use4w = getenv("MISSM_GEMM_4W") ? atoi(getenv("MISSM_GEMM_4W")) : 0;
-  const bool rule4w = use4w == 1 || (use4w == 2 && K <= 1024) || (use4w == 3 && (ngroups > 1 || (K <= 1024 && N <= 1024)));
+  // The row remainder of a split product (27 of the video tower's 197 tile rows at N = 768) is a single partial round whatever runs it:
+  // there the 256x128 kernel replaces the 128x128 one (MISSM_GEMM_TAIL4W=0 restores it).
+  static const int tail4w = getenv("MISSM_GEMM_TAIL4W") ? atoi(getenv("MISSM_GEMM_TAIL4W")) : 1;
+  const bool remainder4w = tail4w && g_row_remainder && ngroups <= 1;
+  const bool rule4w = remainder4w || use4w == 1 || (use4w == 2 && K <= 1024) || (use4w == 3 && (ngroups > 1 || (K <= 1024 && N <= 1024)));
   if (rule4w && dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && K % 64 == 0 && K >= 128 &&
       (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU) &&
       (size_t)lda * 2 * 128 < (size_t(1) << 31) && (size_t)ldb * 2 * 128 < (size_t(1) << 31) &&
-      ((M + 255) / 256) * ((N + 127) / 128) * g.ngroups >= 256) {
+      ((M + 255) / 256) * ((N + 127) / 128) * g.ngroups >= (remainder4w ? 32 : 256)) {
     g.group_tiles_m = (M + 255) / 256;
     g.tiles_m = g.group_tiles_m * g.ngroups; g.tiles_n = (N + 127) / 128;
     g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 8 ? 8 : 1);
@@ -1053,11 +1060,13 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
       if (big_env != 1 && full >= 2 && rem > 0 && rem < 160 && g.ngroups == 1) m_big = (full * 256 / tn2) * 256;
       if (m_big < M) {
         const size_t esz = 2, csz = out_f32 ? 4 : 2;
+        g_row_remainder = 1;
         int rc = missm_gemm(static_cast<const char*>(A) + (size_t)m_big * lda * esz, B, static_cast<char*>(C) + (size_t)m_big * ldc * csz,
                             M - m_big, N, K, lda, ldb, ldc, 0, 0, alpha, bias, resid ? resid + (size_t)m_big * ldc : nullptr,
                             aux_in ? static_cast<const char*>(aux_in) + (size_t)m_big * ldaux * esz : nullptr,
                             aux_out ? static_cast<char*>(aux_out) + (size_t)m_big * ldaux * esz : nullptr, ldaux, act, out_f32,
                             accumulate, 1, nullptr, dtype, stream);
+        g_row_remainder = 0;
         if (rc) return rc;
         g.M = m_big;
       }
