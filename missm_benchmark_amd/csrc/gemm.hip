@@ -1020,7 +1020,15 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
   // The row remainder of a split product (27 of the video tower's 197 tile rows at N = 768) is a single partial round whatever runs it:
   // there the 256x128 kernel replaces the 128x128 one (MISSM_GEMM_TAIL4W=0 restores it).
   static const int tail4w = getenv("MISSM_GEMM_TAIL4W") ? atoi(getenv("MISSM_GEMM_TAIL4W")) : 1;
-  const bool remainder4w = tail4w && g_row_remainder && ngroups <= 1;
+  // ... and so does an ungrouped product that the 256x256 kernel would not take because its grid fills the chip badly (a single
+  // 197-token tower: 75 big tiles at N = 768) but that still has >= 48 tiles of 256x128: it replaces the 128x128 kernel there too.
+  bool small4w = false;
+  if (tail4w && ngroups <= 1 && !g_row_remainder) {
+    const int t2b = ((M + 255) / 256) * ((N + 255) / 256), rb = (t2b + 255) / 256;
+    static const int eff4 = getenv("MISSM_GEMM_BIG_EFF") ? atoi(getenv("MISSM_GEMM_BIG_EFF")) : 75;
+    small4w = !(t2b >= 192 && t2b * 100 >= rb * 256 * eff4) && ((M + 255) / 256) * ((N + 127) / 128) >= 48;
+  }
+  const bool remainder4w = (tail4w && g_row_remainder && ngroups <= 1) || small4w;
   const bool rule4w = remainder4w || use4w == 1 || (use4w == 2 && K <= 1024) || (use4w == 3 && (ngroups > 1 || (K <= 1024 && N <= 1024)));
   if (rule4w && dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && K % 64 == 0 && K >= 128 &&
       (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU) &&
