@@ -316,7 +316,7 @@ def main():
                 print(f"[gemm] M,N,K,tA,tB,act={shape}: {n:4d} launches {t:8.2f} ms  {f / t / 1e9:7.1f} TFLOP/s", file=sys.stderr)
         ach = flops / (ms * 1e-3) / 1e12
         default_workload = set(modalities) == set(MODALITIES) and B == 32 and args.dtype == "bf16"   # what the PMC passes ran
-        roof = {"kernel": "gemm8p_kernel / gemm8p_tn_kernel (+ gemm_kernel<bf16,..> on small shapes): the MFMA GEMM family behind every linear, dX and dW" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
+        roof = {"kernel": "gemm8p_kernel / gemm8p_tn_kernel (+ gemm4w_kernel on row remainders, gemm_kernel<bf16,..> on small shapes): the MFMA GEMM family behind every linear, dX and dW" if args.dtype == "bf16" else "gemm_kernel<float,*>", "bound": "mfma",
                 "achieved": round(ach, 1), "peak": PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3, "unit": "TFLOP/s",
                 "frac": round(ach / (PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3), 4),
                 "traffic": gemm_traffic(len(prof) / (args.steps if inline_prof else 2)) if default_workload else None,

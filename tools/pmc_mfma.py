@@ -15,7 +15,7 @@ p = p.merge(t[["Dispatch_Id", "dur"]], on="Dispatch_Id")
 
 
 def fam(n):
-    for k, f in (("gemm_kernel", "gemm"), ("gemm8p", "gemm"), ("splitk_reduce", "gemm"), ("attn_", "attn"), ("ln_", "ln"), ("adam_kernel", "adam"), ("adam_cast_batched", "adam")):
+    for k, f in (("gemm_kernel", "gemm"), ("gemm8p", "gemm"), ("gemm4w", "gemm"), ("splitk_reduce", "gemm"), ("attn_", "attn"), ("ln_", "ln"), ("adam_kernel", "adam"), ("adam_cast_batched", "adam")):
         if k in n:
             return f
     return "other"

@@ -4,7 +4,7 @@ both counters are in KiB.  Usage: pmc_traffic.py <fetch counter_collection.csv> 
 import json, sys
 import pandas as pd
 
-FAMILIES = (("gemm", ("gemm_kernel", "gemm8p", "splitk_reduce")), ("ln", ("ln_fwd", "ln_bwd")), ("attn", ("attn_",)), ("adam", ("adam_kernel", "adam_cast_batched")))
+FAMILIES = (("gemm", ("gemm_kernel", "gemm8p", "gemm4w", "splitk_reduce")), ("ln", ("ln_fwd", "ln_bwd")), ("attn", ("attn_",)), ("adam", ("adam_kernel", "adam_cast_batched")))
 
 
 def family(name):
@@ -17,7 +17,7 @@ def family(name):
 def load(path, counter):
     d = pd.read_csv(path)
     d = d[d.Counter_Name == counter]
-    d = d.assign(fam=d.Kernel_Name.map(family), is_gemm=d.Kernel_Name.str.contains("gemm_kernel|gemm8p_kernel|gemm8p_tn_kernel"))
+    d = d.assign(fam=d.Kernel_Name.map(family), is_gemm=d.Kernel_Name.str.contains("gemm_kernel|gemm8p_kernel|gemm8p_tn_kernel|gemm4w_kernel"))
     return d
 
 
@@ -26,7 +26,7 @@ f, w = load(sys.argv[1], "FETCH_SIZE"), load(sys.argv[2], "WRITE_SIZE")
 out = {"command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 1 "
                   "--no-cpu-baseline --no-roofline --no-fp32-line --serial-streams",
        "note": "2 steps profiled (1 warm-up + 1 timed). FETCH_SIZE in KiB, doubled per MI355X_MICROARCH.md (gfx950 reports half of wide "
-               "coalesced reads); WRITE_SIZE in KiB.  gemm = gemm8p_kernel + gemm8p_tn_kernel + gemm_kernel + the split-K reduce kernels; its "
+               "coalesced reads); WRITE_SIZE in KiB.  gemm = gemm8p_kernel + gemm8p_tn_kernel + gemm4w_kernel + gemm_kernel + the split-K reduce kernels; its "
                "launches count the tile-kernel dispatches only (a grouped launch is one dispatch).", "kernels": {}}
 for fam in sorted(set(f.fam)):
     ff, ww = f[f.fam == fam], w[w.fam == fam]
