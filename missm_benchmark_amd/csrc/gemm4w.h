@@ -8,8 +8,10 @@
 //   * a wave owns the same 128 x 64 outputs as in gemm8p.h (rows 64 wr + {0, 128} + .., columns 64 wc + ..; 128 accumulator
 //     VGPRs, identical register picture, so the branch-free epilogue gemm8p_store_tile is shared);
 //   * operands travel as 16 KiB half tiles of one K tile (64): B (128 columns), A0 (rows 0-127), A1 (rows 128-255), sequence
-//     number s = 3 t + h, through a ring of FIVE slots (slot = s mod 5): prefetch distance 5 half tiles = 1.67 K tiles, about
-//     what the 8-phase kernel has; the slot of a half tile is free as soon as every wave holds its fragments in registers;
+//     number s = 3 t + h, through a ring of FIVE slots (slot = s mod 5, a run-time index); the slot of a half tile is free as soon
+//     as every wave holds its fragments in registers, and is refilled at once with half tile s + 5: a request is issued two to three
+//     phases (1 to 1.5 K tiles) before the wait that needs it - less slack than the 8-phase kernel's 1.75 K tiles, covered by the
+//     co-resident workgroup;
 //   * a K tile = 2 phases of 32 MFMAs; the fragments of a phase are read one phase ahead, under the previous phase's MFMAs:
 //       phase (t, 0): request s+5, s+6 | read A1(t) | MFMAs A0(t) x B(t) | lgkmcnt(0), vmcnt(8) | barrier
 //       phase (t, 1): request s+7      | read A0(t+1) | MFMAs A1(t) x B(t) | read B(t+1) | lgkmcnt(0), vmcnt(8) | barrier
