@@ -631,6 +631,353 @@ __global__ __launch_bounds__(SPW * 64) void attn_bwd_sp_kernel(AttnArgs a) {
 
 
 // ---------------------------------------------------------------------------------------------------
+// Long sequences (L > 256, head_dim 64, not causal): the released audio checkpoint's 8 x 74 spectrogram grid is 593 tokens per
+// frame - more keys than fit in LDS at once.  K / V travel through LDS in chunks of CK = 14 key tiles (224 keys); a workgroup
+// owns a block of 16 query tiles (two per wave; 8 / one per wave with fp32 operands) of one (sequence, head) and walks the chunks:
+//   forward : online softmax - running row maximum and row sum per query, the O^T accumulators are rescaled when the maximum moves
+//             (the row sum is the ones-row accumulator of the PV product, so it is rescaled by the same multiply);
+//   backward: no rescaling at all (p = exp2(s c - lse) from the saved log-sum-exp): the dQ kernel walks key chunks for a query
+//             block, the dK / dV kernel walks QUERY chunks (Q, dO, lse, D staged per chunk) for a block of 16 key tiles.
+// Same fragment conventions as the kernels above (scores transposed, C-as-operand products); this path trades speed for reach:
+// runtime chunk loops, 256 VGPRs, one workgroup per CU; the fp32 instantiation (parity only) still spills 232-480 bytes per lane.
+// ---------------------------------------------------------------------------------------------------
+constexpr int LCK = 14;                    // key (query) tiles per LDS chunk
+// query (key) tiles per wave of a long-sequence workgroup: two with bf16 operands, one with fp32 (twice the fragment registers)
+template <typename T> constexpr int long_tpw() { return sizeof(T) == 2 ? 2 : 1; }
+
+template <typename T>
+__global__ __launch_bounds__(ATHREADS, 2) void attn_fwd_long_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T);
+  constexpr int LP = LCK * 16;
+  constexpr int KSQ = HD / M_::KS;
+  constexpr int NU = LCK / M_::CTILES;
+  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* ldsK = smem;
+  char* ldsV = smem + LP * RBv;
+  float* kbias = reinterpret_cast<float*>(smem + 2 * LP * RBv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  const int nqb = (((a.L + 15) >> 4) + LQB - 1) / LQB;
+  const int unit = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+  const int seq = unit / a.H, h = unit % a.H;
+  const size_t base = seq_base(a, seq);
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const int L = a.L;
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const int nchunks = (L + LP - 1) / LP;
+
+  Frag qf[TPW][KSQ];
+  float mrun[TPW];
+  f32x4 oacc[TPW][HD / 16], sacc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int qi = (qb * LQB + wave + t * ANW) * 16 + li;
+    sacc[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    mrun[t] = kNegInf;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) oacc[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qf[t][ks] = M_::zero();
+      if (qi < L) qf[t][ks] = *reinterpret_cast<const Frag*>(qkv + (base + (size_t)qi * a.tok_stride) * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+    }
+  }
+  Frag ones = M_::zero();
+  if (li == 0) {
+#pragma unroll
+    for (int j = 0; j < M_::KPL; ++j) ones[j] = (T)1.0f;
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    const int k0 = c * LP, kn = min(L - k0, LP);            // keys of this chunk
+    __syncthreads();                                         // the previous chunk's fragments are all read
+    stage_head<T, RBv, ANW>(ldsK, qkv, base + (size_t)k0 * a.tok_stride, a.tok_stride, a.ld, a.d + h * HD, kn, LP, lane, wave);
+    stage_head<T, RBv, ANW>(ldsV, qkv, base + (size_t)k0 * a.tok_stride, a.tok_stride, a.ld, 2 * a.d + h * HD, kn, LP, lane, wave);
+    for (int k = tid; k < LP; k += ATHREADS)
+      kbias[k] = (k < kn && (!a.key_mask || a.key_mask[(size_t)seq * L + k0 + k] != 0)) ? 0.f : kNegInf;
+    stage_wait<false>();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if ((qb * LQB + wave + t * ANW) * 16 >= L) continue;   // (wave-uniform) no query in this tile
+      f32x4 p[LCK];
+      float mx = kNegInf;
+#pragma unroll
+      for (int kt = 0; kt < LCK; ++kt) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks)
+          acc = M_::step(lds_frag<T>(ldsK + kt * 16 * RBv, swz<RBv>(li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T))), qf[t][ks], acc);
+        acc += *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+        mx = fmaxf(fmaxf(mx, acc[0]), acc[1]);
+        mx = fmaxf(fmaxf(mx, acc[2]), acc[3]);
+        p[kt] = acc;
+      }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      // (no branch on the per-lane maximum: the transposed LDS reads below need every lane.  All keys so far masked: mnew = -inf,
+      //  the probabilities are exp2(-inf) = 0 and the zero accumulators stay zero.)
+      const float mnew = fmaxf(mrun[t], mx);
+      const float alpha = mrun[t] == kNegInf ? 0.f : __builtin_amdgcn_exp2f((mrun[t] - mnew) * sl2);
+      mrun[t] = mnew;
+      const float mxs = mnew == kNegInf ? 0.f : mnew * sl2;
+      sacc[t] *= alpha;
+#pragma unroll
+      for (int dt = 0; dt < HD / 16; ++dt) oacc[t][dt] *= alpha;
+#pragma unroll
+      for (int kt = 0; kt < LCK; ++kt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) p[kt][r] = __builtin_amdgcn_exp2f(p[kt][r] * sl2 - mxs);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        const Frag pf = M_::from_acc(p[u * M_::CTILES], p[u * M_::CTILES + M_::CTILES - 1]);
+        sacc[t] = M_::step(ones, pf, sacc[t]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) oacc[t][dt] = M_::step(TrFrag<T, RBv>::load(ldsV, u * M_::KS, dt * 16, lane), pf, oacc[t][dt]);
+      }
+    }
+  }
+  T* out = static_cast<T*>(a.out);
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int qi = (qb * LQB + wave + t * ANW) * 16 + li;
+    if ((qb * LQB + wave + t * ANW) * 16 >= L) continue;
+    const float sum = __shfl(sacc[t][0], li, 64);
+    const float inv = sum > 0.f ? 1.0f / sum : 0.f;
+    const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
+    if (a.lse && qi < L && lg == 0)
+      a.lse[((size_t)seq * a.H + h) * L + qi] = sum > 0.f ? (mrun[t] * sl2 + __log2f(sum)) * 0.6931471805599453f : kNegInf;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      oacc[t][dt] *= inv;
+      if (qi < L) store4(out + qrow * a.ldo + h * HD + dt * 16 + 4 * lg, oacc[t][dt]);
+    }
+  }
+}
+
+
+// dQ of a block of 16 query tiles: key chunks through LDS (pass A of attn_bwd_mfma_kernel with a chunk loop)
+template <typename T>
+__global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dq_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T);
+  constexpr int LP = LCK * 16;
+  constexpr int KSQ = HD / M_::KS;
+  constexpr int CT = M_::CTILES;
+  constexpr int NU = LCK / CT;
+  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* X0 = smem;                 // K chunk
+  char* X1 = smem + LP * RBv;      // V chunk
+  float* kbias = reinterpret_cast<float*>(smem + 2 * LP * RBv);
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  const int nqb = (((a.L + 15) >> 4) + LQB - 1) / LQB;
+  const int unit = blockIdx.x / nqb, qb = blockIdx.x % nqb;
+  const int seq = unit / a.H, h = unit % a.H;
+  const size_t base = seq_base(a, seq);
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const T* dout = static_cast<const T*>(a.dout);
+  const T* fout = static_cast<const T*>(a.out);
+  T* dqkv = static_cast<T*>(a.dqkv);
+  const int L = a.L;
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const float inv_scale = 1.0f / a.scale;
+  const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
+  const int nchunks = (L + LP - 1) / LP;
+
+  Frag qf[TPW][KSQ], dof[TPW][KSQ];
+  float nlq[TPW], nds[TPW];
+  f32x4 dqa[TPW][HD / 16];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int qi = (qb * LQB + wave + t * ANW) * 16 + li;
+    const size_t qrow = base + (size_t)(qi < L ? qi : 0) * a.tok_stride;
+    float dsum = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      qf[t][ks] = M_::zero(); dof[t][ks] = M_::zero();
+      if (qi < L) {
+        qf[t][ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + h * HD + ks * M_::KS + lg * M_::KPL);
+        dof[t][ks] = *reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL);
+        dsum = frag_dot(dof[t][ks], *reinterpret_cast<const Frag*>(fout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL), dsum);
+      }
+    }
+    dsum += __shfl_xor(dsum, 16, 64);
+    dsum += __shfl_xor(dsum, 32, 64);
+    nds[t] = -dsum;
+    nlq[t] = qi < L ? -lse[qi] * inv_scale : kNegInf;        // (a query past L: S' = -inf, p = 0)
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) dqa[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    const int k0 = c * LP, kn = min(L - k0, LP);
+    __syncthreads();
+    stage_head<T, RBv, ANW>(X0, qkv, base + (size_t)k0 * a.tok_stride, a.tok_stride, a.ld, a.d + h * HD, kn, LP, lane, wave);
+    stage_head<T, RBv, ANW>(X1, qkv, base + (size_t)k0 * a.tok_stride, a.tok_stride, a.ld, 2 * a.d + h * HD, kn, LP, lane, wave);
+    for (int k = tid; k < LP; k += ATHREADS)
+      kbias[k] = (k < kn && (!a.key_mask || a.key_mask[(size_t)seq * L + k0 + k] != 0)) ? 0.f : kNegInf;
+    stage_wait<false>();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if ((qb * LQB + wave + t * ANW) * 16 >= L) continue;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        f32x4 dsv[CT];
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) {
+          const int kt = u * CT + cc;
+          f32x4 sc = {nlq[t], nlq[t], nlq[t], nlq[t]}, dp = {nds[t], nds[t], nds[t], nds[t]};
+#pragma unroll
+          for (int ks = 0; ks < KSQ; ++ks) {
+            const int off = swz<RBv>(kt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+            sc = M_::step(lds_frag<T>(X0, off), qf[t][ks], sc);
+            dp = M_::step(lds_frag<T>(X1, off), dof[t][ks], dp);
+          }
+          sc += *reinterpret_cast<const f32x4*>(kbias + kt * 16 + 4 * lg);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dsv[cc][r] = __builtin_amdgcn_exp2f(sc[r] * sl2) * dp[r];
+        }
+        const Frag dsf = M_::from_acc(dsv[0], dsv[CT - 1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) dqa[t][dt] = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf, dqa[t][dt]);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int qi = (qb * LQB + wave + t * ANW) * 16 + li;
+    if (qi >= L) continue;
+    const size_t qrow = base + (size_t)qi * a.tok_stride;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      dqa[t][dt] *= a.scale;
+      store4(dqkv + qrow * a.ld + h * HD + dt * 16 + 4 * lg, dqa[t][dt]);
+    }
+  }
+}
+
+// dK, dV of a block of 16 key tiles: QUERY chunks (Q, dO, -lse / scale, -D) through LDS (pass B with a chunk loop)
+template <typename T>
+__global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dkv_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T);
+  constexpr int LP = LCK * 16;
+  constexpr int KSQ = HD / M_::KS;
+  constexpr int CT = M_::CTILES;
+  constexpr int NU = LCK / CT;
+  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* X0 = smem;                 // Q chunk
+  char* X1 = smem + LP * RBv;      // dO chunk
+  float* nlse = reinterpret_cast<float*>(smem + 2 * LP * RBv);
+  float* nD = nlse + LP;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  const int nkb = (((a.L + 15) >> 4) + LQB - 1) / LQB;
+  const int unit = blockIdx.x / nkb, kb_ = blockIdx.x % nkb;
+  const int seq = unit / a.H, h = unit % a.H;
+  const size_t base = seq_base(a, seq);
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const T* dout = static_cast<const T*>(a.dout);
+  const T* fout = static_cast<const T*>(a.out);
+  T* dqkv = static_cast<T*>(a.dqkv);
+  const int L = a.L;
+  const float sl2 = a.scale * 1.4426950408889634f;
+  const float inv_scale = 1.0f / a.scale;
+  const float* lse = a.lse + ((size_t)seq * a.H + h) * L;
+  const int nchunks = (L + LP - 1) / LP;
+
+  Frag kf[TPW][KSQ], vf[TPW][KSQ];
+  float kbv[TPW];
+  f32x4 dva[TPW][HD / 16], dka[TPW][HD / 16];
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int key = (kb_ * LQB + wave + t * ANW) * 16 + li;
+    const size_t krow = base + (size_t)(key < L ? key : 0) * a.tok_stride;
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      kf[t][ks] = M_::zero(); vf[t][ks] = M_::zero();
+      if (key < L) {
+        kf[t][ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+        vf[t][ks] = *reinterpret_cast<const Frag*>(qkv + krow * a.ld + 2 * a.d + h * HD + ks * M_::KS + lg * M_::KPL);
+      }
+    }
+    kbv[t] = (key < L && (!a.key_mask || a.key_mask[(size_t)seq * L + key] != 0)) ? 0.f : kNegInf;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) { dva[t][dt] = f32x4{0.f, 0.f, 0.f, 0.f}; dka[t][dt] = dva[t][dt]; }
+  }
+  for (int c = 0; c < nchunks; ++c) {
+    const int q0 = c * LP, qn = min(L - q0, LP);             // queries of this chunk
+    __syncthreads();
+    stage_head<T, RBv, ANW>(X0, qkv, base + (size_t)q0 * a.tok_stride, a.tok_stride, a.ld, h * HD, qn, LP, lane, wave);
+    stage_head<T, RBv, ANW>(X1, dout, base + (size_t)q0 * a.tok_stride, a.tok_stride, a.ldo, h * HD, qn, LP, lane, wave);
+    for (int k = tid; k < LP; k += ATHREADS) nlse[k] = k < qn ? -lse[q0 + k] * inv_scale : kNegInf;
+    for (int qt = wave; qt < LCK; qt += ANW) {               // -D of the chunk's query tiles
+      const int ql = qt * 16 + li;
+      const size_t qrow = base + (size_t)(ql < qn ? q0 + ql : 0) * a.tok_stride;
+      float dsum = 0.f;
+      if (ql < qn) {
+#pragma unroll
+        for (int ks = 0; ks < KSQ; ++ks)
+          dsum = frag_dot(*reinterpret_cast<const Frag*>(dout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL),
+                          *reinterpret_cast<const Frag*>(fout + qrow * a.ldo + h * HD + ks * M_::KS + lg * M_::KPL), dsum);
+      }
+      dsum += __shfl_xor(dsum, 16, 64);
+      dsum += __shfl_xor(dsum, 32, 64);
+      if (lg == 0) nD[ql] = -dsum;
+    }
+    stage_wait<false>();
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+      if ((kb_ * LQB + wave + t * ANW) * 16 >= L) continue;
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        f32x4 pv4[CT], dsv[CT];
+#pragma unroll
+        for (int cc = 0; cc < CT; ++cc) {
+          const int qt = u * CT + cc;
+          f32x4 sc = *reinterpret_cast<const f32x4*>(nlse + qt * 16 + 4 * lg);
+          f32x4 dp = *reinterpret_cast<const f32x4*>(nD + qt * 16 + 4 * lg);
+#pragma unroll
+          for (int ks = 0; ks < KSQ; ++ks) {
+            const int off = swz<RBv>(qt * 16 + li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+            sc = M_::step(lds_frag<T>(X0, off), kf[t][ks], sc);
+            dp = M_::step(lds_frag<T>(X1, off), vf[t][ks], dp);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float pv = __builtin_amdgcn_exp2f(sc[r] * sl2 + kbv[t]);
+            pv4[cc][r] = pv;
+            dsv[cc][r] = pv * dp[r];
+          }
+        }
+        const Frag pf = M_::from_acc(pv4[0], pv4[CT - 1]);
+        const Frag dsf = M_::from_acc(dsv[0], dsv[CT - 1]);
+#pragma unroll
+        for (int dt = 0; dt < HD / 16; ++dt) {
+          dva[t][dt] = M_::step(TrFrag<T, RBv>::load(X1, u * M_::KS, dt * 16, lane), pf, dva[t][dt]);
+          dka[t][dt] = M_::step(TrFrag<T, RBv>::load(X0, u * M_::KS, dt * 16, lane), dsf, dka[t][dt]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; ++t) {
+    const int key = (kb_ * LQB + wave + t * ANW) * 16 + li;
+    if (key >= L) continue;
+    const size_t krow = base + (size_t)key * a.tok_stride;
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      dka[t][dt] *= a.scale;
+      store4(dqkv + krow * a.ld + a.d + h * HD + dt * 16 + 4 * lg, dka[t][dt]);
+      store4(dqkv + krow * a.ld + 2 * a.d + h * HD + dt * 16 + 4 * lg, dva[t][dt]);
+    }
+  }
+}
+
+
+// ---------------------------------------------------------------------------------------------------
 // Small-sequence path (L <= 32, any head_dim <= 128 that is a multiple of 8): the video tower's temporal
 // attention (L = T = 8, B*197 sequences x 12 heads) and the tiny parity configs.  No MFMA: one wavefront
 // packs 64 / L (sequence, head) pairs, lane = (pair, query); operands sit in LDS as T, math in fp32.
@@ -857,7 +1204,28 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
 #undef MISSM_SMALL
     return missm_check_launch("attn_small");
   }
-  if (hd != HD || L > 256) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64 and L<=256)", L, hd); return MISSM_ERR_INVALID; }
+  if (hd != HD) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64)", L, hd); return MISSM_ERR_INVALID; }
+  if (L > 256) {                 // key-chunked kernels (the 593-token spectrogram grid of the released audio checkpoint)
+    if (a.causal) { missm_set_error("attention: causal attention over more than 256 tokens is not instantiated"); return MISSM_ERR_INVALID; }
+    constexpr int LQBh = long_tpw<T>() * ANW;
+    const int nqb = (((L + 15) / 16) + LQBh - 1) / LQBh;
+    const dim3 grid_l(a.nseq * a.H * nqb), block_l(ATHREADS);
+    if constexpr (BWD) {
+      const size_t sh_dq = (size_t)2 * LCK * 16 * HD * sizeof(T) + (size_t)LCK * 16 * 4, sh_kv = (size_t)2 * LCK * 16 * HD * sizeof(T) + (size_t)2 * LCK * 16 * 4;
+      auto kq = attn_bwd_long_dq_kernel<T>;
+      auto kk = attn_bwd_long_dkv_kernel<T>;
+      int rc = launch_dyn(kq, grid_l, block_l, sh_dq, s, "attn_bwd_long_dq"); if (rc) return rc;
+      rc = launch_dyn(kk, grid_l, block_l, sh_kv, s, "attn_bwd_long_dkv"); if (rc) return rc;
+      hipLaunchKernelGGL(kq, grid_l, block_l, sh_dq, s, a);
+      hipLaunchKernelGGL(kk, grid_l, block_l, sh_kv, s, a);
+    } else {
+      const size_t sh = (size_t)2 * LCK * 16 * HD * sizeof(T) + (size_t)LCK * 16 * 4;
+      auto k = attn_fwd_long_kernel<T>;
+      int rc = launch_dyn(k, grid_l, block_l, sh, s, "attn_fwd_long"); if (rc) return rc;
+      hipLaunchKernelGGL(k, grid_l, block_l, sh, s, a);
+    }
+    return missm_check_launch("attn_long");
+  }
   dim3 grid(a.nseq * a.H);
   if constexpr (BWD && sizeof(T) == 2) {
     // single-pass backward (attn_bwd_sp_kernel), opt-in: measured slower than the two-pass kernel (see its header)

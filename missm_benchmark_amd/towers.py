@@ -85,9 +85,10 @@ class ClipTower(nn.Module):
             raise ValueError("head_dim must be a multiple of 8")
         if c.kind == "vision" and (c.patch_size % 4 or c.image_hw[0] % c.patch_size or c.image_hw[1] % c.patch_size):
             raise ValueError("patch_size must be a multiple of 4 and divide image_size")
-        if c.kind == "vision" and c.seq_len > 256 and c.hidden_size // c.num_attention_heads == 64:
-            raise NotImplementedError(f"{c.seq_len} tokens per frame: the attention kernels keep a head's whole K and V in LDS and cover "
-                                      "up to 256 tokens (the released audio checkpoint's 8 x 74 spectrogram grid needs a key-tiled variant)")
+        if c.seq_len > 256 and c.hidden_size // c.num_attention_heads != 64:
+            raise NotImplementedError(f"{c.seq_len} tokens per sequence need head_dim 64 (the key-chunked attention kernels)")
+        if c.kind != "vision" and c.seq_len > 256:
+            raise NotImplementedError("causal attention over more than 256 tokens is not instantiated")
         if c.kind == "vision" and c.force_patch_dropout:
             raise NotImplementedError("force_patch_dropout > 0 (random token dropping in training, image/modeling_image.py:30-63) is not "
                                       "implemented; the default configuration uses 0")

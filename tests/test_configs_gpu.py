@@ -394,6 +394,30 @@ def test_lockstep_tower_groups_equal_separate_towers(pkg):
     assert rel(runs[True][0][:2], ologits) < 5e-2
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_spectrogram_tower_with_more_than_256_tokens_vs_oracle(pkg, dtype):
+    """a (112, 1040) spectrogram image is a 7 x 65 patch grid: 456 tokens per frame, more keys than the attention kernels hold in LDS
+    at once - the key-chunked kernels (online softmax forward, chunked dQ / dK-dV backward) against the CPU oracle (the released
+    audio checkpoint's 8 x 74 grid is the same code path)."""
+    cfg = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=(112, 1040), patch_size=16)
+    ocfg = O.VisionCfg(**cfg)
+    params = O.init_tower_params(ocfg, 6)
+    assert params["embeddings.position_embedding.weight"].shape[0] == 456
+    tower = make_tower(pkg, cfg, "vision", params, dtype)
+    x = torch.randn(2, 3, 112, 1040, generator=torch.Generator().manual_seed(8))
+    last, pooled = tower(x.cuda())
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    olast, opooled = O.vision_tower(x, p, ocfg)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert rel(pooled, opooled) < tol and rel(last, olast) < tol
+    cot = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(3))
+    (pooled * cot.cuda()).sum().backward()
+    (opooled * cot).sum().backward()
+    for k in ("embeddings.position_embedding.weight", "encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.0.self_attn.v_proj.weight",
+              "encoder.layers.1.mlp.fc1.weight"):
+        assert grad_ok(k, tower.get_parameter(k).grad, p[k].grad, 2e-3, dtype), k
+
+
 def test_non_square_spectrogram_tower_vs_oracle(pkg):
     """the audio model's (num_mel_bins, target_length) image (reference resize_pos, image/modeling_image.py:795-839): a tower over a
     2 x 4 patch grid against the CPU oracle, forward and gradients, fp32 instantiation"""

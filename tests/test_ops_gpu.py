@@ -332,6 +332,12 @@ CASES = [  # name, nseq-structure
     dict(name="sp_s100", B=2, T=1, S=100, H=1, hd=64, temporal=False, causal=False, mask=True),
     dict(name="sp_s130_t2", B=1, T=2, S=130, H=2, hd=64, temporal=False, causal=False, mask=False),
     dict(name="sp_s224", B=1, T=1, S=224, H=2, hd=64, temporal=False, causal=False, mask=False),
+    # more than 256 tokens (key-chunked kernels): the 593-token spectrogram grid of the released audio checkpoint, a key mask that
+    # cuts into the second chunk, exactly two chunks, and a ragged third chunk with two frames per sample
+    dict(name="long_s593", B=2, T=1, S=593, H=2, hd=64, temporal=False, causal=False, mask=False),
+    dict(name="long_s300_mask", B=3, T=1, S=300, H=1, hd=64, temporal=False, causal=False, mask=True),
+    dict(name="long_s448", B=1, T=1, S=448, H=2, hd=64, temporal=False, causal=False, mask=False),
+    dict(name="long_s460_t2", B=1, T=2, S=460, H=1, hd=64, temporal=False, causal=False, mask=True),
 ]
 
 
