@@ -244,8 +244,10 @@ extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, c
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd: cols must be a positive multiple of 4");
   LnBwdArgs a{dy, dy_div > 0 ? dy_div : 1, dy_scale, x, in_mul > 0 ? in_mul : 1, in_off, mean, rstd, gamma, dx, accumulate,
               dgamma, dbeta, rows, cols, dx_cast};
-  // grid cap: 1024 workgroups is the fastest stand-alone (4.8 TB/s), 768 the fastest inside the two-stream step (+0.7 %)
-  static const int cap = getenv("MISSM_LN_BLOCKS") ? atoi(getenv("MISSM_LN_BLOCKS")) : 768;
+  // grid cap: round 1's kernel (one row in flight per wave) wanted 768-1024 workgroups; with the rows software-pipelined two
+  // workgroups per CU already keep the memory pipe full, and fewer blocks mean fewer dgamma / dbeta atomics and less pressure on
+  // the second stream: inside the two-stream step 512 measures 463.5 samples/s against 460.4 at 768 and 462.9 at 384
+  static const int cap = getenv("MISSM_LN_BLOCKS") ? atoi(getenv("MISSM_LN_BLOCKS")) : 512;
   int blocks = (rows + 3) / 4;
   if (blocks > cap) blocks = cap;
   dim3 grid(blocks), block(256);
