@@ -632,28 +632,29 @@ __global__ __launch_bounds__(SPW * 64) void attn_bwd_sp_kernel(AttnArgs a) {
 
 // ---------------------------------------------------------------------------------------------------
 // Long sequences (L > 256, head_dim 64, not causal): the released audio checkpoint's 8 x 74 spectrogram grid is 593 tokens per
-// frame - more keys than fit in LDS at once.  K / V travel through LDS in chunks of CK = 14 key tiles (224 keys); a workgroup
+// frame - more keys than fit in LDS at once.  K / V travel through LDS in chunks of 14 key tiles (224 keys; 8 with fp32); a workgroup
 // owns a block of 16 query tiles (two per wave; 8 / one per wave with fp32 operands) of one (sequence, head) and walks the chunks:
 //   forward : online softmax - running row maximum and row sum per query, the O^T accumulators are rescaled when the maximum moves
 //             (the row sum is the ones-row accumulator of the PV product, so it is rescaled by the same multiply);
 //   backward: no rescaling at all (p = exp2(s c - lse) from the saved log-sum-exp): the dQ kernel walks key chunks for a query
 //             block, the dK / dV kernel walks QUERY chunks (Q, dO, lse, D staged per chunk) for a block of 16 key tiles.
 // Same fragment conventions as the kernels above (scores transposed, C-as-operand products); this path trades speed for reach:
-// runtime chunk loops, 256 VGPRs, one workgroup per CU; the fp32 instantiation (parity only) still spills 232-480 bytes per lane.
+// runtime chunk loops, up to 256 VGPRs, one workgroup per CU.
 // ---------------------------------------------------------------------------------------------------
-constexpr int LCK = 14;                    // key (query) tiles per LDS chunk
+// key (query) tiles per LDS chunk: 14 (224 keys) with bf16 operands, 8 with fp32 (the fully unrolled chunk body otherwise spills)
+template <typename T> constexpr int long_ck() { return sizeof(T) == 2 ? 14 : 8; }
 // query (key) tiles per wave of a long-sequence workgroup: two with bf16 operands, one with fp32 (twice the fragment registers)
 template <typename T> constexpr int long_tpw() { return sizeof(T) == 2 ? 2 : 1; }
 
 template <typename T>
 __global__ __launch_bounds__(ATHREADS, 2) void attn_fwd_long_kernel(AttnArgs a) {
+  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW, LCK = long_ck<T>();
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
   constexpr int LP = LCK * 16;
   constexpr int KSQ = HD / M_::KS;
   constexpr int NU = LCK / M_::CTILES;
-  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* ldsK = smem;
   char* ldsV = smem + LP * RBv;
@@ -759,6 +760,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_fwd_long_kernel(AttnArgs a) 
 // dQ of a block of 16 query tiles: key chunks through LDS (pass A of attn_bwd_mfma_kernel with a chunk loop)
 template <typename T>
 __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dq_kernel(AttnArgs a) {
+  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW, LCK = long_ck<T>();
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
@@ -766,7 +768,6 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dq_kernel(AttnArgs 
   constexpr int KSQ = HD / M_::KS;
   constexpr int CT = M_::CTILES;
   constexpr int NU = LCK / CT;
-  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* X0 = smem;                 // K chunk
   char* X1 = smem + LP * RBv;      // V chunk
@@ -860,6 +861,7 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dq_kernel(AttnArgs 
 // dK, dV of a block of 16 key tiles: QUERY chunks (Q, dO, -lse / scale, -D) through LDS (pass B with a chunk loop)
 template <typename T>
 __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dkv_kernel(AttnArgs a) {
+  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW, LCK = long_ck<T>();
   using M_ = Mma<T>;
   using Frag = typename M_::Frag;
   constexpr int RBv = HD * sizeof(T);
@@ -867,7 +869,6 @@ __global__ __launch_bounds__(ATHREADS, 2) void attn_bwd_long_dkv_kernel(AttnArgs
   constexpr int KSQ = HD / M_::KS;
   constexpr int CT = M_::CTILES;
   constexpr int NU = LCK / CT;
-  constexpr int TPW = long_tpw<T>(), LQB = TPW * ANW;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* X0 = smem;                 // Q chunk
   char* X1 = smem + LP * RBv;      // dO chunk
@@ -1211,7 +1212,8 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
     const int nqb = (((L + 15) / 16) + LQBh - 1) / LQBh;
     const dim3 grid_l(a.nseq * a.H * nqb), block_l(ATHREADS);
     if constexpr (BWD) {
-      const size_t sh_dq = (size_t)2 * LCK * 16 * HD * sizeof(T) + (size_t)LCK * 16 * 4, sh_kv = (size_t)2 * LCK * 16 * HD * sizeof(T) + (size_t)2 * LCK * 16 * 4;
+      constexpr int LCKh = long_ck<T>();
+      const size_t sh_dq = (size_t)2 * LCKh * 16 * HD * sizeof(T) + (size_t)LCKh * 16 * 4, sh_kv = (size_t)2 * LCKh * 16 * HD * sizeof(T) + (size_t)2 * LCKh * 16 * 4;
       auto kq = attn_bwd_long_dq_kernel<T>;
       auto kk = attn_bwd_long_dkv_kernel<T>;
       int rc = launch_dyn(kq, grid_l, block_l, sh_dq, s, "attn_bwd_long_dq"); if (rc) return rc;
@@ -1219,7 +1221,8 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
       hipLaunchKernelGGL(kq, grid_l, block_l, sh_dq, s, a);
       hipLaunchKernelGGL(kk, grid_l, block_l, sh_kv, s, a);
     } else {
-      const size_t sh = (size_t)2 * LCK * 16 * HD * sizeof(T) + (size_t)LCK * 16 * 4;
+      constexpr int LCKh = long_ck<T>();
+      const size_t sh = (size_t)2 * LCKh * 16 * HD * sizeof(T) + (size_t)LCKh * 16 * 4;
       auto k = attn_fwd_long_kernel<T>;
       int rc = launch_dyn(k, grid_l, block_l, sh, s, "attn_fwd_long"); if (rc) return rc;
       hipLaunchKernelGGL(k, grid_l, block_l, sh, s, a);
