@@ -122,7 +122,8 @@ int missm_attention_bwd(const void* qkv, const void* out, const void* dout, cons
                         const int* key_mask, float scale, int dtype, void* stream);
 
 /* Patch unfold: pixels fp32 (frame n = (b, t): base b*stride_b + t*stride_t, channel stride_c, row-major HxW) ->
- * A[n*P + p, c*ps*ps + ky*ps + kx] of type `dtype` (the conv weight's .view(d, -1) order). */
+ * A[n*P + p, c*ps*ps + ky*ps + kx] of type `dtype` (the conv weight's .view(d, -1) order).
+ * Rows hold Kp = C*ps*ps rounded up to a multiple of 8 elements (zero columns behind K: a 14-pixel patch has K = 588). */
 int missm_unfold_patches(const float* pixels, void* out, int B, int T, int C, int H, int W, int ps, long stride_b,
                          long stride_t, long stride_c, int dtype, void* stream);
 /* out[r] = in[rdiv > 0 ? r + r / rdiv + roff : r] converted fp32 -> `dtype` (residual-gradient stream -> GEMM operand;

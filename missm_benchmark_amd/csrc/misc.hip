@@ -5,11 +5,13 @@
 namespace missm {
 
 // ---- patch unfold: the k = stride = ps conv (video/modeling_video.py:29-35) becomes a GEMM over these rows ----
-template <typename T>
+// Output rows hold Kp = K rounded up to a multiple of 8 elements (16-byte GEMM operand rows; K = C * ps * ps): Kp == K whenever
+// ps % 4 == 0, a 14-pixel patch (K = 588) gets 4 zero columns.  VEC: ps % 4 == 0 - four consecutive kx share a pixel row.
+template <typename T, bool VEC>
 __global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ px, T* __restrict__ out, int B, int Tn, int C, int H,
                                                     int W, int ps, long sb, long st, long sc) {
-  const int gw = W / ps, gh = H / ps, P = gw * gh, K = C * ps * ps;
-  const int quads = K / 4;                       // ps % 4 == 0: 4 consecutive kx share a pixel row
+  const int gw = W / ps, gh = H / ps, P = gw * gh, K = C * ps * ps, Kp = (K + 7) / 8 * 8;
+  const int quads = Kp / 4;
   const long total = (long)B * Tn * P * quads;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const int qd = idx % quads;
@@ -17,10 +19,23 @@ __global__ __launch_bounds__(256) void unfold_kernel(const float* __restrict__ p
     const int p = rowi % P;
     const long n = rowi / P;
     const int b = n / Tn, t = n % Tn;
-    const int k = qd * 4, c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
     const int py = p / gw, pxx = p % gw;
-    const float* src = px + b * sb + t * st + c * sc + (long)(py * ps + ky) * W + pxx * ps + kx;
-    store4(out + rowi * K + k, load4(src));
+    const float* img = px + b * sb + t * st;
+    if constexpr (VEC) {
+      const int k = qd * 4, c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
+      store4(out + rowi * Kp + k, load4(img + c * sc + (long)(py * ps + ky) * W + pxx * ps + kx));
+    } else {
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int k = qd * 4 + j;
+        if (k < K) {
+          const int c = k / (ps * ps), rem = k % (ps * ps), ky = rem / ps, kx = rem % ps;
+          v[j] = img[c * sc + (long)(py * ps + ky) * W + pxx * ps + kx];
+        }
+      }
+      store4(out + rowi * Kp + qd * 4, v);
+    }
   }
 }
 
@@ -567,12 +582,14 @@ using namespace missm;
 
 extern "C" int missm_unfold_patches(const float* pixels, void* out, int B, int T, int C, int H, int W, int ps, long stride_b,
                                     long stride_t, long stride_c, int dtype, void* stream) {
-  MISSM_CHECK_ARG(B > 0 && T > 0 && C > 0 && ps > 0 && ps % 4 == 0 && H % ps == 0 && W % ps == 0, "unfold: bad shape (patch size must be a multiple of 4)");
-  MISSM_CHECK_ARG(W % 4 == 0 && stride_b % 4 == 0 && stride_t % 4 == 0 && stride_c % 4 == 0, "unfold: strides must keep 16-byte alignment");
-  const long total = (long)B * T * (H / ps) * (W / ps) * (C * ps * ps / 4);
+  MISSM_CHECK_ARG(B > 0 && T > 0 && C > 0 && ps > 0 && H % ps == 0 && W % ps == 0, "unfold: bad shape (the patch size must divide the image)");
+  const bool vec = ps % 4 == 0 && W % 4 == 0 && stride_b % 4 == 0 && stride_t % 4 == 0 && stride_c % 4 == 0;
+  const long total = (long)B * T * (H / ps) * (W / ps) * ((C * ps * ps + 7) / 8 * 2);
   dim3 grid(grid_for(total, 8192)), block(256);
-  if (dtype == kBF16) hipLaunchKernelGGL(unfold_kernel<bf16>, grid, block, 0, S_(stream), pixels, (bf16*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c);
-  else hipLaunchKernelGGL(unfold_kernel<float>, grid, block, 0, S_(stream), pixels, (float*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c);
+#define MISSM_UNFOLD(TT, VV) hipLaunchKernelGGL((unfold_kernel<TT, VV>), grid, block, 0, S_(stream), pixels, (TT*)out, B, T, C, H, W, ps, stride_b, stride_t, stride_c)
+  if (dtype == kBF16) { if (vec) MISSM_UNFOLD(bf16, true); else MISSM_UNFOLD(bf16, false); }
+  else { if (vec) MISSM_UNFOLD(float, true); else MISSM_UNFOLD(float, false); }
+#undef MISSM_UNFOLD
   return missm_check_launch("unfold_patches");
 }
 

@@ -19,31 +19,38 @@ from torch import nn
 ALIGN = 64  # floats (256 B): keeps every block 16-byte aligned for vector loads and the atomics' 256-B runs
 
 
-class Block:
-    """Contiguous run of parameters (no padding inside): [(name, shape), ...]"""
+def _stored(shape, pitch) -> int:
+    """floats an item occupies: contiguous, or rows of `pitch` floats (first dimension = rows, the rest padded up to the pitch)"""
+    return int(torch.Size(shape).numel()) if pitch is None else int(shape[0]) * int(pitch)
 
-    def __init__(self, items: Sequence[Tuple[str, Tuple[int, ...]]], kind: str):
+
+class Block:
+    """Contiguous run of parameters: [(name, shape) | (name, shape, pitch), ...].  With a pitch the tensor's first dimension is
+    stored as rows of `pitch` floats (zero padding behind the row's own elements: the patch-embedding matrix of a 14-pixel patch
+    has 588 columns, the GEMM wants a multiple of 8) and the parameter is a strided view."""
+
+    def __init__(self, items: Sequence[Tuple], kind: str):
         assert kind in ("mat", "vec")
-        self.items = list(items)
+        self.items = [(it[0], tuple(it[1]), (it[2] if len(it) > 2 else None)) for it in items]
         self.kind = kind
         self.offset = -1
-        self.numel = sum(int(torch.Size(s).numel()) for _, s in items)
+        self.numel = sum(_stored(s, pitch) for _, s, pitch in self.items)
 
 
 class FlatStore:
     def __init__(self, blocks: List[Block]):
         self.blocks = [b for b in blocks if b.kind == "mat"] + [b for b in blocks if b.kind == "vec"]
         off = 0
-        self.index: Dict[str, Tuple[int, Tuple[int, ...]]] = {}
+        self.index: Dict[str, Tuple] = {}          # name -> (offset, shape, row pitch or None)
         self.vec_start = None
         for b in self.blocks:
             if b.kind == "vec" and self.vec_start is None:
                 self.vec_start = off
             b.offset = off
             o = off
-            for name, shape in b.items:
-                self.index[name] = (o, tuple(shape))
-                o += int(torch.Size(shape).numel())
+            for name, shape, pitch in b.items:
+                self.index[name] = (o, tuple(shape), pitch)
+                o += _stored(shape, pitch)
             off = (o + ALIGN - 1) // ALIGN * ALIGN
         self.total = off
         if self.vec_start is None:
@@ -52,13 +59,20 @@ class FlatStore:
         self.grad = None
 
     # ---- views -------------------------------------------------------------------------------
+    @staticmethod
+    def _item_view(buf: torch.Tensor, o: int, shape, pitch) -> torch.Tensor:
+        if pitch is None:
+            return buf[o:o + int(torch.Size(shape).numel())].view(shape)
+        inner = [1]
+        for n in reversed(shape[2:]):
+            inner.insert(0, inner[0] * n)
+        return buf.as_strided(shape, (pitch, *inner), buf.storage_offset() + o)
+
     def view(self, name: str) -> torch.Tensor:
-        o, shape = self.index[name]
-        return self.master[o:o + int(torch.Size(shape).numel())].view(shape)
+        return self._item_view(self.master, *self.index[name])
 
     def gview(self, name: str) -> torch.Tensor:
-        o, shape = self.index[name]
-        return self.grad[o:o + int(torch.Size(shape).numel())].view(shape)
+        return self._item_view(self.grad, *self.index[name])
 
     def block_view(self, block: Block, buf: torch.Tensor) -> torch.Tensor:
         return buf[block.offset:block.offset + block.numel]

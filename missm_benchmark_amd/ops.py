@@ -257,7 +257,7 @@ def attention_bwd(qkv, out, dout, lse, dqkv, nseq, L, H, hd, *, seq_div=1, seq_o
 
 
 def unfold_patches(pixels: torch.Tensor, out: torch.Tensor, ps: int):
-    """pixels fp32 [N,C,H,W] or [B,C,T,H,W] -> out[(n p), C*ps*ps]."""
+    """pixels fp32 [N,C,H,W] or [B,C,T,H,W] -> out[(n p), Kp], Kp = C*ps*ps rounded up to a multiple of 8 (zero columns behind K)."""
     if pixels.dim() == 4:
         B, Cc, H, W = pixels.shape
         T, sb, st, sc = 1, pixels.stride(0), 0, pixels.stride(1)
@@ -267,7 +267,7 @@ def unfold_patches(pixels: torch.Tensor, out: torch.Tensor, ps: int):
     if pixels.stride(-1) != 1 or pixels.stride(-2) != W or pixels.dtype != torch.float32:
         raise _lib.MissmError("unfold_patches: need fp32 pixels with contiguous HxW planes")
     P = (H // ps) * (W // ps)
-    if out.shape[0] < B * T * P or out.shape[1] != Cc * ps * ps:
+    if out.shape[0] < B * T * P or out.shape[1] != (Cc * ps * ps + 7) // 8 * 8 or not out.is_contiguous():
         raise _lib.MissmError("unfold_patches: bad output")
     _lib.call("missm_unfold_patches", pixels.data_ptr(), out.data_ptr(), B, T, Cc, H, W, ps, sb, st, sc, dt(out), _s())
     return out

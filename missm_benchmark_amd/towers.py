@@ -83,8 +83,8 @@ class ClipTower(nn.Module):
             raise NotImplementedError("temporal_mlp (image-family add_time_attn branch) is not on the HIP path yet")
         if c.hidden_size % c.num_attention_heads or (c.hidden_size // c.num_attention_heads) % 8:
             raise ValueError("head_dim must be a multiple of 8")
-        if c.kind == "vision" and (c.patch_size % 4 or c.image_hw[0] % c.patch_size or c.image_hw[1] % c.patch_size):
-            raise ValueError("patch_size must be a multiple of 4 and divide image_size")
+        if c.kind == "vision" and (c.image_hw[0] % c.patch_size or c.image_hw[1] % c.patch_size or c.image_hw[1] % 4):
+            raise ValueError("patch_size must divide image_size (and the image width must be a multiple of 4)")
         if c.seq_len > 256 and c.hidden_size // c.num_attention_heads != 64:
             raise NotImplementedError(f"{c.seq_len} tokens per sequence need head_dim 64 (the key-chunked attention kernels)")
         if c.kind != "vision" and c.seq_len > 256:
@@ -100,7 +100,11 @@ class ClipTower(nn.Module):
         if c.kind == "vision":
             # (appended AFTER the layers' matrices: the backward finishes with the embeddings, so the last gradient bucket -
             #  patch embedding + every vector parameter - is one contiguous range of the flat buffer)
-            patch_block = Block([("embeddings.patch_embedding.weight", (d, c.num_channels, c.patch_size, c.patch_size))], "mat")
+            # (rows of the patch matrix padded to a multiple of 8 floats: a 14-pixel patch has 3 * 14 * 14 = 588 columns, the GEMM
+            #  operands need 16-byte rows; the parameter is a strided view, the padding stays zero)
+            kp = c.num_channels * c.patch_size ** 2
+            patch_block = Block([("embeddings.patch_embedding.weight", (d, c.num_channels, c.patch_size, c.patch_size),
+                                  None if kp % 8 == 0 else (kp + 7) // 8 * 8)], "mat")
             blocks.append(Block([("embeddings.class_embedding", (d,)), ("embeddings.position_embedding.weight", (c.seq_len, d)),
                                  ("pre_layrnorm.weight", (d,)), ("pre_layrnorm.bias", (d,))], "vec"))
         else:
@@ -251,7 +255,7 @@ class ClipTower(nn.Module):
             entries = []
             self._cast_tile_range = []          # (flat offset of the block, first tile, tile count) in table order
             for key, b in self._mat_blocks.items():
-                n_out = sum(s[0] for _, s in b.items)
+                n_out = sum(it[1][0] for it in b.items)
                 k_in = b.numel // n_out
                 src = st.block_view(b, st.master).view(n_out, k_in)
                 w = src if T == torch.float32 else torch.empty(n_out, k_in, device=src.device, dtype=T)
@@ -308,7 +312,7 @@ class ClipTower(nn.Module):
             L = SimpleNamespace()
 
             def vec3(prefix, buf):
-                o, _ = st.index[f"{p}.{prefix}.q_proj.bias"]
+                o = st.index[f"{p}.{prefix}.q_proj.bias"][0]
                 return buf[o:o + 3 * d]
 
             L.qkv_b, L.g_qkv_b = vec3("self_attn", st.master), vec3("self_attn", st.grad)
@@ -318,7 +322,7 @@ class ClipTower(nn.Module):
                 setattr(L, nm, st.view(f"{p}.{key}")); setattr(L, "g_" + nm, st.gview(f"{p}.{key}"))
             for key in ("qkv", "out", "fc1", "fc2"):
                 b = self._mat_blocks[f"{p}.{key}"]
-                n_out = sum(s[0] for _, s in b.items)
+                n_out = sum(it[1][0] for it in b.items)
                 setattr(L, "g_" + key + "_w", st.block_view(b, st.grad).view(n_out, b.numel // n_out))
             if c.add_time_attn:
                 L.tqkv_b, L.g_tqkv_b = vec3("temporal_attn", st.master), vec3("temporal_attn", st.grad)
@@ -329,7 +333,7 @@ class ClipTower(nn.Module):
                 L.g_temb = st.gview(f"{p}.temporal_embedding").view(c.num_frames, d)
                 for key in ("tqkv", "tout"):
                     b = self._mat_blocks[f"{p}.{key}"]
-                    n_out = sum(s[0] for _, s in b.items)
+                    n_out = sum(it[1][0] for it in b.items)
                     setattr(L, "g_" + key + "_w", st.block_view(b, st.grad).view(n_out, b.numel // n_out))
             self._lp.append(L)
 
@@ -484,7 +488,7 @@ def forward_lanes(towers, inputs, save: bool):
             pxs.append(px)
         N = B * Tf
         P = S - 1
-        Kp = c.num_channels * c.patch_size ** 2
+        Kp = (c.num_channels * c.patch_size ** 2 + 7) // 8 * 8      # (padded like the patch matrix's rows)
         U = E(N * P, Kp, device=dev, dtype=T)
         for g in G:
             ops.unfold_patches(pxs[g], U[g], c.patch_size)

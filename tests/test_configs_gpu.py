@@ -418,6 +418,47 @@ def test_spectrogram_tower_with_more_than_256_tokens_vs_oracle(pkg, dtype):
         assert grad_ok(k, tower.get_parameter(k).grad, p[k].grad, 2e-3, dtype), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_patch14_tower_with_257_tokens_vs_oracle(pkg, dtype):
+    """the geometry of the released ViT-L/14-class checkpoints: 14-pixel patches on a 224 x 224 image = 256 patches + CLS = 257 tokens.
+    The patch matrix has 3 * 14 * 14 = 588 columns (rows padded to 592 in the flat store, the parameter is a strided view whose padding
+    stays zero through Adam); 257 tokens take the key-chunked attention kernels.  Forward, gradients (patch embedding included) and one
+    Adam step against the CPU oracle."""
+    cfg = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=224, patch_size=14)
+    ocfg = O.VisionCfg(**cfg)
+    params = O.init_tower_params(ocfg, 9)
+    assert params["embeddings.patch_embedding.weight"].shape == (128, 3, 14, 14)
+    tower = make_tower(pkg, cfg, "vision", params, dtype)
+    w = tower.get_parameter("embeddings.patch_embedding.weight")
+    assert w.shape == (128, 3, 14, 14) and not w.is_contiguous() and torch.equal(w.detach().cpu(), params["embeddings.patch_embedding.weight"])
+    x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))
+    last, pooled = tower(x.cuda())
+    p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    olast, opooled = O.vision_tower(x, p, ocfg)
+    tol = TOL32 if dtype == torch.float32 else 3e-2
+    assert rel(pooled, opooled) < tol and rel(last, olast) < tol
+    cot = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(3))
+    (pooled * cot.cuda()).sum().backward()
+    (opooled * cot).sum().backward()
+    for k in ("embeddings.patch_embedding.weight", "embeddings.position_embedding.weight", "encoder.layers.0.self_attn.k_proj.weight",
+              "encoder.layers.1.mlp.fc2.weight"):
+        assert grad_ok(k, tower.get_parameter(k).grad, p[k].grad, 2e-3, dtype), k
+    # one Adam step through the engine: the padded columns of the patch matrix stay exactly zero, the real ones move like torch's Adam
+    from missm_benchmark_amd.engine import TrainEngine
+    own_grad = w.grad.detach().cpu().clone()       # (the first Adam step is lr * sign(g): compare on the tower's own gradient)
+    eng = TrainEngine(tower, lr=1e-3)
+    eng.step()
+    torch.cuda.synchronize()
+    flat = tower.flat_master()
+    b = tower._mat_blocks["patch"]
+    blk = flat[b.offset:b.offset + b.numel].view(128, 592)
+    assert float(blk[:, 588:].abs().max()) == 0.0
+    ref = p["embeddings.patch_embedding.weight"].detach().clone().requires_grad_(True)
+    ref.grad = own_grad
+    torch.optim.Adam([ref], lr=1e-3).step()
+    assert rel(w, ref.detach()) < 1e-5
+
+
 def test_non_square_spectrogram_tower_vs_oracle(pkg):
     """the audio model's (num_mel_bins, target_length) image (reference resize_pos, image/modeling_image.py:795-839): a tower over a
     2 x 4 patch grid against the CPU oracle, forward and gradients, fp32 instantiation"""

@@ -115,3 +115,26 @@ def test_apply_adam_refuses_cpu():
     from missm_benchmark_amd import _lib
     with pytest.raises(_lib.MissmError, match="no CPU fallback"):
         model({"image": {"pixel_values": torch.zeros(1, 3, 32, 32)}}, torch.zeros(1, dtype=torch.int64))
+
+
+def test_patch14_matrix_is_a_padded_strided_view():
+    """a 14-pixel patch embedding has 3 * 14 * 14 = 588 columns: its rows are stored 592 floats apart in the flat buffer (16-byte GEMM
+    operand rows), the state-dict entry keeps the reference's shape, a state-dict round trip fills exactly the real columns and the
+    padding stays zero."""
+    sys.path.insert(0, ROOT)
+    from missm_benchmark_amd.towers import ClipTower, TowerConfig
+    cfg = TowerConfig(kind="vision", hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=28, patch_size=14)
+    a, b = ClipTower(cfg), ClipTower(cfg)
+    a.reset_parameters(1); b.reset_parameters(2)
+    w = a.get_parameter("embeddings.patch_embedding.weight")
+    assert w.shape == (32, 3, 14, 14) and w.stride() == (592, 196, 14, 1)
+    sd = a.state_dict()
+    assert sd["embeddings.patch_embedding.weight"].shape == (32, 3, 14, 14)
+    b.load_state_dict({k: v.clone() for k, v in sd.items()})
+    assert torch.equal(b.get_parameter("embeddings.patch_embedding.weight"), w)
+    blk = b._mat_blocks["patch"]
+    rows = b.flat_master()[blk.offset:blk.offset + blk.numel].view(32, 592)
+    assert torch.equal(rows[:, :588].reshape(32, 3, 14, 14), w.detach()) and float(rows[:, 588:].abs().max()) == 0.0
+    # a 16-pixel patch needs no padding: contiguous as before
+    c16 = ClipTower(TowerConfig(kind="vision", hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=32, patch_size=16))
+    assert c16.get_parameter("embeddings.patch_embedding.weight").is_contiguous()
