@@ -1206,7 +1206,11 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
     return missm_check_launch("attn_small");
   }
   if (hd != HD) { missm_set_error("attention: L=%d head_dim=%d unsupported (need L<=32, or head_dim 64)", L, hd); return MISSM_ERR_INVALID; }
-  if (L > 256) {                 // key-chunked kernels (the 593-token spectrogram grid of the released audio checkpoint)
+  // (257 .. 288 tokens with bf16 operands - ViT-L/14 at 224 x 224 is 257 - still fit the LDS-resident kernels: NTP = 18, 72 KiB,
+  //  two workgroups per CU; MISSM_ATTN_NTP18=0 sends them to the key-chunked kernels)
+  static const int ntp18 = getenv("MISSM_ATTN_NTP18") ? atoi(getenv("MISSM_ATTN_NTP18")) : 1;
+  const bool lds18 = ntp18 && sizeof(T) == 2 && L > 256 && L <= 288 && !a.causal;
+  if (L > 256 && !lds18) {       // key-chunked kernels (the 593-token spectrogram grid of the released audio checkpoint)
     if (a.causal) { missm_set_error("attention: causal attention over more than 256 tokens is not instantiated"); return MISSM_ERR_INVALID; }
     constexpr int LQBh = long_tpw<T>() * ANW;
     const int nqb = (((L + 15) / 16) + LQBh - 1) / LQBh;
@@ -1268,7 +1272,8 @@ template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipSt
       hipLaunchKernelGGL(k, grid, block, shmem, s, a);                                                       \
     }                                                                                                       \
   } while (0)
-  if (L <= 96) MISSM_MFMA(6); else if (L <= 224) MISSM_MFMA(14); else MISSM_MFMA(16);
+  if (L <= 96) MISSM_MFMA(6); else if (L <= 224) MISSM_MFMA(14); else if (L <= 256) MISSM_MFMA(16);
+  else { if constexpr (sizeof(T) == 2) MISSM_MFMA(18); }
 #undef MISSM_MFMA
   return missm_check_launch("attn_mfma");
 }

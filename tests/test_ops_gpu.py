@@ -338,6 +338,9 @@ CASES = [  # name, nseq-structure
     dict(name="long_s300_mask", B=3, T=1, S=300, H=1, hd=64, temporal=False, causal=False, mask=True),
     dict(name="long_s448", B=1, T=1, S=448, H=2, hd=64, temporal=False, causal=False, mask=False),
     dict(name="long_s460_t2", B=1, T=2, S=460, H=1, hd=64, temporal=False, causal=False, mask=True),
+    # 257 .. 288 tokens (ViT-L/14 at 224 x 224 is 257): bf16 stays on the LDS-resident kernels (NTP = 18), fp32 takes the chunked ones
+    dict(name="lds18_s257", B=2, T=1, S=257, H=2, hd=64, temporal=False, causal=False, mask=False),
+    dict(name="lds18_s288_mask", B=2, T=1, S=288, H=1, hd=64, temporal=False, causal=False, mask=True),
 ]
 
 

@@ -22,7 +22,7 @@ def timed(fn, iters=20):
 NSEQ = [int(x) for x in sys.argv[1].split(",")] if len(sys.argv) > 1 else (256, 128, 32)
 ITERS = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 for nseq in NSEQ:
-    L, H, hd = 197, 12, 64
+    L, H, hd = int(os.environ.get("ATTN_L", "197")), 12, 64
     rows = nseq * L
     qkv = (torch.randn(rows, 3 * H * hd, device="cuda") * 0.5).to(torch.bfloat16)
     out = torch.empty(rows, H * hd, device="cuda", dtype=torch.bfloat16)
