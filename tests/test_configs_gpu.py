@@ -418,19 +418,21 @@ def test_spectrogram_tower_with_more_than_256_tokens_vs_oracle(pkg, dtype):
         assert grad_ok(k, tower.get_parameter(k).grad, p[k].grad, 2e-3, dtype), k
 
 
+@pytest.mark.parametrize("width", [(128, 256, 2), (1024, 4096, 16)], ids=["d128", "vit_l_width"])
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_patch14_tower_with_257_tokens_vs_oracle(pkg, dtype):
+def test_patch14_tower_with_257_tokens_vs_oracle(pkg, dtype, width):
     """the geometry of the released ViT-L/14-class checkpoints: 14-pixel patches on a 224 x 224 image = 256 patches + CLS = 257 tokens.
     The patch matrix has 3 * 14 * 14 = 588 columns (rows padded to 592 in the flat store, the parameter is a strided view whose padding
     stays zero through Adam); 257 tokens take the key-chunked attention kernels.  Forward, gradients (patch embedding included) and one
     Adam step against the CPU oracle."""
-    cfg = dict(hidden_size=128, intermediate_size=256, num_hidden_layers=2, num_attention_heads=2, image_size=224, patch_size=14)
+    d, f, heads = width                 # (the second one is the ViT-L/14 layer: d = 1024, 16 heads of 64, MLP 4096; two layers of it)
+    cfg = dict(hidden_size=d, intermediate_size=f, num_hidden_layers=2, num_attention_heads=heads, image_size=224, patch_size=14)
     ocfg = O.VisionCfg(**cfg)
     params = O.init_tower_params(ocfg, 9)
-    assert params["embeddings.patch_embedding.weight"].shape == (128, 3, 14, 14)
+    assert params["embeddings.patch_embedding.weight"].shape == (d, 3, 14, 14)
     tower = make_tower(pkg, cfg, "vision", params, dtype)
     w = tower.get_parameter("embeddings.patch_embedding.weight")
-    assert w.shape == (128, 3, 14, 14) and not w.is_contiguous() and torch.equal(w.detach().cpu(), params["embeddings.patch_embedding.weight"])
+    assert w.shape == (d, 3, 14, 14) and not w.is_contiguous() and torch.equal(w.detach().cpu(), params["embeddings.patch_embedding.weight"])
     x = torch.randn(2, 3, 224, 224, generator=torch.Generator().manual_seed(8))
     last, pooled = tower(x.cuda())
     p = {k: v.clone().requires_grad_(True) for k, v in params.items()}
@@ -451,7 +453,7 @@ def test_patch14_tower_with_257_tokens_vs_oracle(pkg, dtype):
     torch.cuda.synchronize()
     flat = tower.flat_master()
     b = tower._mat_blocks["patch"]
-    blk = flat[b.offset:b.offset + b.numel].view(128, 592)
+    blk = flat[b.offset:b.offset + b.numel].view(d, 592)
     assert float(blk[:, 588:].abs().max()) == 0.0
     ref = p["embeddings.patch_embedding.weight"].detach().clone().requires_grad_(True)
     ref.grad = own_grad
