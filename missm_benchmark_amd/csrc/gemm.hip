@@ -1028,12 +1028,16 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
     static const int eff4 = getenv("MISSM_GEMM_BIG_EFF") ? atoi(getenv("MISSM_GEMM_BIG_EFF")) : 75;
     small4w = !(t2b >= 192 && t2b * 100 >= rb * 256 * eff4) && ((M + 255) / 256) * ((N + 127) / 128) >= 48;
   }
-  const bool remainder4w = (tail4w && g_row_remainder && ngroups <= 1) || small4w;
+  // ... and the UNGROUPED products with K <= 1024 and N <= 1024 (the video tower's out-projections and their dX: three tile columns, an
+  // epilogue-heavy K = 768 main loop): on the big lane alone the 256x128 kernel pays inside the two-stream step too, +0.6 %
+  // (456.8 vs 454.1 samples/s, three alternating runs) - it was putting the small towers' grouped launches on it that cost.
+  const bool out4w = tail4w && ngroups <= 1 && !g_row_remainder && K <= 1024 && N <= 1024;
+  const bool remainder4w = (tail4w && g_row_remainder && ngroups <= 1) || small4w || out4w;
   const bool rule4w = remainder4w || use4w == 1 || (use4w == 2 && K <= 1024) || (use4w == 3 && (ngroups > 1 || (K <= 1024 && N <= 1024)));
   if (rule4w && dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && K % 64 == 0 && K >= 128 &&
       (act == MISSM_ACT_NONE || act == MISSM_ACT_QGELU || act == MISSM_ACT_DQGELU) &&
       (size_t)lda * 2 * 128 < (size_t(1) << 31) && (size_t)ldb * 2 * 128 < (size_t(1) << 31) &&
-      ((M + 255) / 256) * ((N + 127) / 128) * g.ngroups >= (remainder4w ? 32 : 256)) {
+      ((M + 255) / 256) * ((N + 127) / 128) * g.ngroups >= (out4w && !small4w ? 256 : (remainder4w ? 32 : 256))) {
     g.group_tiles_m = (M + 255) / 256;
     g.tiles_m = g.group_tiles_m * g.ngroups; g.tiles_n = (N + 127) / 128;
     g.group_m = group_m_env > 0 ? group_m_env : (g.tiles_n >= 8 ? 8 : 1);
