@@ -28,6 +28,7 @@ import types
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")   # kernel arguments staged in device memory (see missm_benchmark_amd/__init__.py): set before torch loads HIP
 
 MODALITIES = ["image", "audio", "depth", "thermal", "video"]   # video last in forward => first in backward (largest all-reduce overlaps the rest)
 PEAK_BF16_TFLOPS = 2500.0   # dense, /opt/skills/guides/MI355X_MICROARCH.md

@@ -3,9 +3,18 @@
 ``install()`` registers this package's drop-in modules under the reference's import names so that reference-style code
 (``from languagebind import LanguageBind``; ``from src.model.baseline import finetune_model``) runs on this build.
 """
+import os as _os
 import sys as _sys
 
 __all__ = ["install"]
+
+# HIP places kernel arguments in host-coherent memory by default; every workgroup of every launch fetches them from there (the GEMM
+# kernels carry up to eight operand sets by value, ~0.7 KB).  HIP_FORCE_DEV_KERNARG=1 makes the runtime stage them in device memory:
+# +1.6 % on the training step (466.7 vs 459.3 samples/s, three alternating runs).  The runtime reads the flag when it initialises,
+# i.e. at `import torch` - so this only takes effect when this package (or bench.py) is imported BEFORE torch; an explicit setting
+# of the variable in the environment always wins.
+if "torch" not in _sys.modules:
+    _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 
 def install():
