@@ -3,6 +3,7 @@
 set -uo pipefail
 OUT=${1:-gpurun_out/insitu}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export HIP_FORCE_DEV_KERNARG=1   # (bench.py sets it itself, but under rocprofv3 the profiler initialises HIP before python starts)
 mkdir -p $OUT
 export MISSM_GEMM_LOG=$OUT/shapes.log
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/tr -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-fp32-line --serial-streams > $OUT/line.json 2> $OUT/err.txt || { tail -5 $OUT/err.txt; exit 1; }

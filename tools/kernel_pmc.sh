@@ -5,6 +5,7 @@ set -uo pipefail
 OUT=${1:-gpurun_out/attn_pmc}; shift || true
 ARGS=("$@"); [ ${#ARGS[@]} -eq 0 ] && ARGS=(tools/attn_bench.py 256 4)
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export HIP_FORCE_DEV_KERNARG=1   # (bench.py sets it itself, but under rocprofv3 the profiler initialises HIP before python starts)
 mkdir -p $OUT
 i=0
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS" \

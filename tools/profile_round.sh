@@ -3,6 +3,7 @@
 # line (with fp32 line and CPU baseline), and the bench lines of configs[1] / configs[4].  Run on the GPU box from the repo root.
 set -uo pipefail
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
+export HIP_FORCE_DEV_KERNARG=1   # (bench.py sets it itself, but under rocprofv3 the profiler initialises HIP before python starts)
 R=gpurun_out/r02
 mkdir -p $R
 B="python3 bench.py --no-cpu-baseline --no-fp32-line --serial-streams"
