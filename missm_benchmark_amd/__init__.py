@@ -6,15 +6,20 @@
 import os as _os
 import sys as _sys
 
-__all__ = ["install"]
+__all__ = ["install", "kernarg_mode"]
 
-# HIP places kernel arguments in host-coherent memory by default; every workgroup of every launch fetches them from there (the GEMM
-# kernels carry up to eight operand sets by value, ~0.7 KB).  HIP_FORCE_DEV_KERNARG=1 makes the runtime stage them in device memory:
-# +1.6 % on the training step (466.7 vs 459.3 samples/s, three alternating runs).  The runtime reads the flag when it initialises,
-# i.e. at `import torch` - so this only takes effect when this package (or bench.py) is imported BEFORE torch; an explicit setting
-# of the variable in the environment always wins.
-if "torch" not in _sys.modules:
-    _os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+# Kernel-argument placement: HIP puts kernel arguments in host-coherent memory by default and every workgroup of every
+# launch fetches them from there (the GEMM kernels carry up to eight operand sets by value, ~0.7 KB); HIP_FORCE_DEV_KERNARG=1 stages
+# them in device memory, +1.6 % on the training step.  The runtime reads the variable once, when it initialises (at `import torch`),
+# and the setting is process-wide (torch's own kernels and RCCL see it too) - so it is the ENTRY POINTS that default it (bench.py,
+# `python -m missm_benchmark_amd.train_ddp`, tests/conftest.py), never this library: importing the package changes no environment.
+# `kernarg_mode()` reports what the process runs with; `_lib.load()` says so once when the variable is unset.
+
+
+def kernarg_mode() -> str:
+    """'device' (HIP_FORCE_DEV_KERNARG=1), 'host' (=0) or 'default (host-coherent)' when the variable is unset"""
+    v = _os.environ.get("HIP_FORCE_DEV_KERNARG")
+    return "default (host-coherent)" if v is None else ("device" if v == "1" else "host")
 
 
 def install():

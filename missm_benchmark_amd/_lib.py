@@ -87,6 +87,12 @@ def load():
         fn.restype = res
     if lib.missm_abi_version() != ABI_VERSION:
         raise MissmError("libmissm_hip.so ABI version mismatch; rebuild")
+    if "HIP_FORCE_DEV_KERNARG" not in os.environ:
+        # (the library never sets process-wide environment itself - see missm_benchmark_amd/__init__.py)
+        import warnings
+        warnings.warn("HIP_FORCE_DEV_KERNARG is unset: kernel arguments stay in host-coherent memory (about -1.6 % on the training "
+                      "step).  Export HIP_FORCE_DEV_KERNARG=1 before torch is imported, as bench.py and the train_ddp CLI do.",
+                      RuntimeWarning, stacklevel=2)
     _lib = lib
     return lib
 

@@ -240,13 +240,33 @@ class TrainEngine:
         if self.world == 1 and self.update_stream is not None:
             torch.cuda.current_stream().wait_stream(self.update_stream)   # the towers' bucket-wise updates
 
+    def _buffer_index(self, t) -> int:
+        """position of a tower's (or, for None, the flattened remainder's) buffer in flat_buffers() - the key of its Adam moments"""
+        if t is None:
+            return len(self.towers)
+        for i, x in enumerate(self.towers):
+            if x is t:
+                return i
+        raise KeyError("tower is not optimised by this engine")
+
+    def _moments(self, master, t):
+        """Adam moments of one flat buffer, keyed by the buffer's POSITION (keyed by ``master.data_ptr()`` a rebind of the
+        tower - ``model.to(device)``, ``set_compute_dtype`` - silently dropped restored moments while the step count kept its value).
+        Moments follow the buffer to its device; a buffer whose size changed is an error, not a restart from zero."""
+        key = self._buffer_index(t)
+        mv = self._state.get(key)
+        if mv is None:
+            mv = self._state[key] = (torch.zeros_like(master), torch.zeros_like(master))
+        elif mv[0].numel() != master.numel():
+            raise RuntimeError("TrainEngine: the optimizer state of a flat buffer does not match its size (model changed after load_state_dict?)")
+        elif mv[0].device != master.device:
+            mv = self._state[key] = (mv[0].to(master.device), mv[1].to(master.device))
+        return mv
+
     def _adam_on(self, master, grad, t, flat_range=None):
         if not master.is_cuda:
             raise RuntimeError("TrainEngine.apply_adam: parameters are not on a GPU (no CPU optimizer path)")
-        key = master.data_ptr()
-        if key not in self._state:
-            self._state[key] = (torch.zeros_like(master), torch.zeros_like(master))
-        m, v = self._state[key]
+        m, v = self._moments(master, t)
         hp = (self.step_count + 1, self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
         if flat_range is not None:
             # one gradient bucket of a tower: the weight matrices that start inside it, and - if it is the tail range (it ends
@@ -288,26 +308,99 @@ class TrainEngine:
         self.apply_adam()
 
     # ---- optimizer state (checkpoint 'optimizer_state_dict', reference train_ddp.py:298-306) -----------------------
+    def _located_params(self):
+        """[(name, parameter, flat-buffer index or None, element offset)] in ``model.named_parameters()`` order - the order in which
+        ``optim.Adam(model.parameters())`` (reference train_ddp.py:205) numbers its state"""
+        bufs = [(m.data_ptr(), m.data_ptr() + 4 * m.numel()) for m, _, _ in self.flat_buffers()]
+        out = []
+        for name, p in self.model.named_parameters():
+            where = None
+            for i, (lo, hi) in enumerate(bufs):
+                if lo <= p.data_ptr() < hi:
+                    where = (i, (p.data_ptr() - lo) // 4)
+                    break
+            out.append((name, p, where))
+        return out
+
     def state_dict(self):
-        """step count, hyper-parameters and the Adam moments of every flat buffer (in flat_buffers() order), on the CPU"""
-        torch.cuda.synchronize() if torch.cuda.is_available() else None
-        flat = []
-        for master, _, _ in self.flat_buffers():
-            mv = self._state.get(master.data_ptr())
-            flat.append(None if mv is None else {"exp_avg": mv[0].detach().cpu(), "exp_avg_sq": mv[1].detach().cpu()})
-        return {"step": self.step_count, "lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd,
-                "flat": flat}
+        """``torch.optim.Adam.state_dict()`` layout (what the reference saves, train_ddp.py:303): ``{'state': {i: {'step', 'exp_avg',
+        'exp_avg_sq'}}, 'param_groups': [{lr, betas, eps, weight_decay, amsgrad, ..., 'params': [0..n-1], 'param_names': [...]}]}``
+        with ``i`` numbering ``model.parameters()``; every per-parameter moment is the parameter-shaped slice of the flat moment
+        buffers (padding rows of the padded patch matrix are not part of it).  ``param_names`` (as recent torch writes for
+        optimizers built from named parameters) lets a loader match by name when module registration order differs."""
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        bufs = self.flat_buffers()
+        state, names = {}, []
+        for i, (name, p, where) in enumerate(self._located_params()):
+            names.append(name)
+            if where is None:
+                continue
+            mv = self._state.get(where[0])
+            if mv is None or self.step_count == 0:
+                continue
+            master = bufs[where[0]][0]
+            off = where[1] + mv[0].storage_offset()
+            state[i] = {"step": torch.tensor(float(self.step_count)),
+                        "exp_avg": mv[0].as_strided(p.shape, p.stride(), off).detach().cpu().contiguous().clone(),
+                        "exp_avg_sq": mv[1].as_strided(p.shape, p.stride(), off).detach().cpu().contiguous().clone()}
+            assert master.numel() == mv[0].numel()
+        group = {"lr": self.lr, "betas": tuple(self.betas), "eps": self.eps, "weight_decay": self.wd, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "decoupled_weight_decay": False,
+                 "params": list(range(len(names))), "param_names": names}
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
+        """accepts ``torch.optim.Adam.state_dict()`` (with ``param_names``: matched by name; without: by position, shapes checked) and
+        the round-2 private layout (``{'flat': [...]}``)"""
         bufs = self.flat_buffers()
-        if len(sd["flat"]) != len(bufs):
-            raise ValueError("optimizer state does not match this model's flat buffers")
-        self.step_count, self.lr, self.betas, self.eps, self.wd = sd["step"], sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
-        for (master, _, _), st in zip(bufs, sd["flat"]):
-            if st is None:
-                self._state.pop(master.data_ptr(), None)
-                continue
-            if st["exp_avg"].numel() != master.numel():
+        if "flat" in sd:                              # round-2 checkpoints
+            if len(sd["flat"]) != len(bufs):
                 raise ValueError("optimizer state does not match this model's flat buffers")
-            self._state[master.data_ptr()] = (st["exp_avg"].to(master.device, torch.float32).clone(),
-                                              st["exp_avg_sq"].to(master.device, torch.float32).clone())
+            self.step_count, self.lr, self.betas, self.eps, self.wd = sd["step"], sd["lr"], tuple(sd["betas"]), sd["eps"], sd["weight_decay"]
+            for i, ((master, _, _), st) in enumerate(zip(bufs, sd["flat"])):
+                if st is None:
+                    self._state.pop(i, None)
+                    continue
+                if st["exp_avg"].numel() != master.numel():
+                    raise ValueError("optimizer state does not match this model's flat buffers")
+                self._state[i] = (st["exp_avg"].to(master.device, torch.float32).clone(), st["exp_avg_sq"].to(master.device, torch.float32).clone())
+            return
+        if "state" not in sd or "param_groups" not in sd or len(sd["param_groups"]) != 1:
+            raise ValueError("optimizer state: expected torch.optim.Adam's {'state', 'param_groups'} with one parameter group")
+        grp = sd["param_groups"][0]
+        if grp.get("amsgrad"):
+            raise ValueError("optimizer state: amsgrad is not implemented by the fused Adam kernel")
+        located = self._located_params()
+        ids = list(grp["params"])
+        names = grp.get("param_names")
+        if names is not None:
+            by_name = dict(zip(names, ids))
+            missing = [n for n, _, w in located if w is not None and n not in by_name]
+            if missing:
+                raise ValueError(f"optimizer state lacks parameters {missing[:4]}{' ...' if len(missing) > 4 else ''}")
+            pick = [by_name.get(n) for n, _, _ in located]
+        else:
+            if len(ids) != len(located):
+                raise ValueError(f"optimizer state numbers {len(ids)} parameters, the model has {len(located)}")
+            pick = ids
+        self.lr, self.betas, self.eps, self.wd = grp["lr"], tuple(grp["betas"]), grp["eps"], grp["weight_decay"]
+        self._state = {}
+        steps = set()
+        for (name, p, where), idx in zip(located, pick):
+            st = sd["state"].get(idx) if idx is not None else None
+            if st is None or where is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError(f"optimizer state of {name}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")
+            master = bufs[where[0]][0]
+            if where[0] not in self._state:
+                self._state[where[0]] = (torch.zeros_like(master), torch.zeros_like(master))
+            m, v = self._state[where[0]]
+            off = where[1] + m.storage_offset()
+            m.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg"].to(m.device, torch.float32))
+            v.as_strided(p.shape, p.stride(), off).copy_(st["exp_avg_sq"].to(v.device, torch.float32))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError(f"optimizer state: parameters disagree on the step count {sorted(steps)} (one fused step per flat buffer)")
+        self.step_count = steps.pop() if steps else 0

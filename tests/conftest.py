@@ -1,6 +1,10 @@
 import os
 import sys
 
+# the test session is an entry point: run the kernels the way bench.py does (kernel arguments staged in device memory); must
+# happen before anything imports torch (missm_benchmark_amd/__init__.py); an explicit setting in the environment wins
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -481,3 +481,123 @@ def test_non_square_spectrogram_tower_vs_oracle(pkg):
         assert rel(tower.get_parameter(k).grad, p[k].grad) < 2e-3, k
     with pytest.raises(ValueError):
         tower(torch.randn(1, 3, 64, 32).cuda())               # height / width swapped
+
+
+def _oracle_grad_lookup(tp, proj, fp):
+    def get(k):
+        if k.startswith("encoder.modality_encoder."):
+            m = k.split(".")[2]
+            return tp[m][k[len(f"encoder.modality_encoder.{m}."):]].grad
+        if k.startswith("encoder.modality_proj."):
+            return proj[k.split(".")[2]].grad
+        return fp[k[len("fusion."):]].grad
+    return get
+
+
+def test_config2_full_batch_b32_vs_oracle_every_row(pkg):
+    """BASELINE.json configs[2] / [3] at the size the metric is quoted on - five full ViT-B/16 towers, B = 32, `sum` fusion under
+    `synth_missing_index(32, mods, 0.3, 2025)`, CE, full backward - against the CPU oracle on ALL 32 logits rows and on named
+    gradients of every tower (VERDICT r2 #3c; the other B = 32 tests compare 4 rows).  The oracle differentiates the same batch in
+    micro-batches of 4 samples (CE `sum` / 32: the samples are independent and the loss is their mean, so the accumulated gradient
+    IS the full-batch gradient; 32 samples at once would hold ~60 GB of fp32 attention probabilities).
+      fp32 instantiation: logits 1e-3, loss 1e-3, gradients 1e-3 in relative Frobenius norm (and the suite's 4e-3 worst-element bar);
+      bf16 instantiation: logits 5e-2, gradients by direction, magnitude and the per-class Frobenius bound of `grad_ok`."""
+    from missm_benchmark_amd.data import synth_missing_index
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    from test_towers_gpu import fro
+    mods = ["video", "image", "audio", "depth", "thermal"]
+    T = pkg.towers.TowerConfig
+    cfgs = {m: T(kind="vision", add_time_attn=(m == "video"), num_frames=8 if m == "video" else 1) for m in mods}
+    enc = pkg.lb.LanguageBind({m: f"LanguageBind_{m.capitalize()}" for m in mods}, configs=cfgs, compute_dtype=torch.float32, seed=9)
+    args = types.SimpleNamespace(modality_types=mods, feature_dims=768, fusion_dim=256, dropout_prob=0.0, fusion_type="sum")
+    torch.manual_seed(0)
+    model = pkg.base.finetune_model(args, 8, enc)
+    sd = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    B, MB = 32, 4
+    missing = synth_missing_index(B, mods, 0.3, 2025)
+    g = torch.Generator().manual_seed(123)
+    data = {m: {"pixel_values": torch.randn(*((B, 3, 8, 224, 224) if m == "video" else (B, 3, 224, 224)), generator=g)} for m in mods}
+    labels = torch.randint(0, 8, (B,), generator=g)
+    tp, ocfg, proj, scales, fp = _oracle_parts(sd, mods)
+    rows, oloss = [], 0.0
+    for lo in range(0, B, MB):
+        sub = {m: {"pixel_values": data[m]["pixel_values"][lo:lo + MB]} for m in mods}
+        lg, _ = O.finetune_forward(sub, missing[lo:lo + MB], tp, ocfg, proj, scales, fp, mods)
+        part = torch.nn.functional.cross_entropy(lg, labels[lo:lo + MB], reduction="sum") / B
+        part.backward()
+        rows.append(lg.detach())
+        oloss += float(part.detach())
+    ologits = torch.cat(rows)
+    oracle_grad = _oracle_grad_lookup(tp, proj, fp)
+    per_tower = ["encoder.layers.0.self_attn.q_proj.weight", "encoder.layers.6.self_attn.k_proj.weight", "encoder.layers.11.self_attn.v_proj.weight",
+                 "encoder.layers.5.self_attn.out_proj.weight", "encoder.layers.0.mlp.fc1.weight", "encoder.layers.11.mlp.fc2.weight",
+                 "embeddings.patch_embedding.weight", "embeddings.position_embedding.weight", "embeddings.class_embedding",
+                 "encoder.layers.3.layer_norm1.weight", "encoder.layers.9.layer_norm2.bias", "encoder.layers.2.mlp.fc1.bias",
+                 "encoder.layers.7.self_attn.out_proj.bias", "pre_layrnorm.weight", "post_layernorm.bias"]
+    video_only = ["encoder.layers.0.temporal_attn.q_proj.weight", "encoder.layers.8.temporal_attn.out_proj.weight",
+                  "encoder.layers.4.temporal_embedding", "encoder.layers.10.temporal_layer_norm1.weight", "encoder.layers.1.temporal_attn.v_proj.bias"]
+    names = [f"encoder.modality_encoder.{m}.{k}" for m in mods for k in per_tower] + \
+            [f"encoder.modality_encoder.video.{k}" for k in video_only] + \
+            [f"encoder.modality_proj.{m}.weight" for m in mods] + [f"fusion.modal_proj.{m}.weight" for m in mods] + \
+            ["fusion.modal_proj.depth.bias", "fusion.norm.weight", "fusion.head.head.0.weight", "fusion.head.head.3.bias"]
+    model = model.cuda()
+    gdata = _to_gpu(data)
+    for dtype, tol in ((torch.float32, TOL32), (torch.bfloat16, 5e-2)):
+        enc.set_compute_dtype(dtype)
+        model.zero_grad(set_to_none=True)
+        logits = model(gdata, missing.cuda())
+        loss = HipCrossEntropyLoss()(logits, labels.cuda())
+        loss.backward()
+        assert logits.shape == ologits.shape == (B, 8)
+        assert rel(logits, ologits) < tol, dtype                               # every one of the 32 rows
+        assert abs(float(loss.detach()) - oloss) < tol * max(1.0, oloss), dtype
+        for k in names:
+            mine, ref = model.get_parameter(k).grad, oracle_grad(k)
+            assert mine is not None and ref is not None, k
+            if dtype == torch.float32:
+                assert fro(mine, ref) < 1e-3, (k, fro(mine, ref))
+            assert grad_ok(k, mine, ref, tol * 4, dtype), (k, dtype)
+        torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, TOL32), (torch.bfloat16, TOLBF)])
+def test_config4_video_tower_b16_vs_oracle(pkg, dtype, tol):
+    """BASELINE.json configs[4] at its own shape: the video tower alone, B = 16 x 8 frames x 197 tokens (25 216 rows: the dispatcher
+    takes the 256 x 128 kernel for the ungrouped products here, unlike the B = 32 / B = 2 runs - VERDICT r2 weak #3), forward +
+    backward.  The cotangent is non-zero on two of the sixteen samples only: the weight gradients of the B = 16 run are then the
+    oracle's gradients of those two samples (every other sample's rows enter the GEMMs with zero upstream gradient), the pooled
+    outputs of the two are compared with the oracle directly, and the other fourteen through batch independence against a B = 2 run
+    of the same tower (a different tile dispatch again)."""
+    cfg = pkg.towers.TowerConfig(kind="vision", add_time_attn=True, num_frames=8)
+    ocfg = O.VisionCfg(add_time_attn=True, num_frames=8)
+    params = O.init_tower_params(ocfg, seed=31)
+    tower = pkg.towers.ClipTower(cfg, compute_dtype=dtype)
+    tower.load_state_dict(params, strict=True)
+    tower = tower.cuda()
+    B, pick = 16, [3, 11]
+    x = torch.randn(B, 3, 8, 224, 224, generator=torch.Generator().manual_seed(17))
+    cot_p = torch.zeros(B, 768)
+    cot_p[pick] = torch.randn(2, 768, generator=torch.Generator().manual_seed(18))
+    cot_l = torch.zeros(B * 8, 197, 768)
+    for s in pick:                                                  # (the last hidden state's cotangent too, on the same two samples)
+        cot_l[s * 8:(s + 1) * 8] = 0.05 * torch.randn(8, 197, 768, generator=torch.Generator().manual_seed(19 + s))
+    op = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    olast, opooled = O.vision_tower(x[pick], op, ocfg)
+    ((opooled * cot_p[pick]).sum() + (olast * torch.cat([cot_l[s * 8:(s + 1) * 8] for s in pick])).sum()).backward()
+    last, pooled = tower(x.cuda())
+    assert last.shape == (B * 8, 197, 768) and pooled.shape == (B, 768)
+    ((pooled * cot_p.cuda()).sum() + (last * cot_l.cuda()).sum()).backward()
+    assert rel(pooled[pick], opooled) < tol
+    rows = torch.cat([torch.arange(s * 8, (s + 1) * 8) for s in pick])
+    assert rel(last[rows.cuda()], olast) < tol
+    names = ["encoder.layers.0.temporal_attn.q_proj.weight", "encoder.layers.11.temporal_attn.out_proj.weight", "encoder.layers.5.temporal_embedding",
+             "encoder.layers.0.self_attn.v_proj.weight", "encoder.layers.6.self_attn.out_proj.weight", "encoder.layers.3.mlp.fc1.weight",
+             "encoder.layers.11.mlp.fc2.weight", "encoder.layers.2.mlp.fc2.bias", "encoder.layers.9.layer_norm1.weight",
+             "encoder.layers.4.temporal_layer_norm1.bias", "embeddings.patch_embedding.weight", "embeddings.position_embedding.weight",
+             "pre_layrnorm.bias", "post_layernorm.weight"]
+    for k in names:
+        assert grad_ok(k, tower.get_parameter(k).grad, op[k].grad, tol * 4, dtype), k
+    with torch.no_grad():                                           # batch independence of the other fourteen (B = 2 runs, another dispatch)
+        for lo in (0, 8, 14):
+            _, p2 = tower(x[lo:lo + 2].cuda())
+            assert rel(p2, pooled[lo:lo + 2]) < (1e-4 if dtype == torch.float32 else 1e-2), lo

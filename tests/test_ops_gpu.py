@@ -300,6 +300,34 @@ def test_layernorm_add_and_gather(ops):
     assert rel(dx, xr.grad) < 2e-5
 
 
+@pytest.mark.parametrize("idt", DTYPES)
+def test_layernorm_bwd_gather_multi_trip(ops, idt):
+    """The software-pipelined backward on its row-GATHER path (in_off + in_mul, dy_div > 1) with more rows than 4 x the
+    capped grid (512 workgroups): every wave makes two or three trips and the last trip of most waves has no successor row, so the look-ahead
+    `issue(row + rstep)` is exercised at its guard (an unguarded look-ahead reads in_off / mean / rstd past the end
+    and turns the garbage offset into a wild row address - the abort recorded in round 2)."""
+    n, S, d, T = 4 * 512 * 2 + 5, 3, 256, 3           # 4101 gathered rows, 3 candidates each; dy shared by T consecutive rows
+    ndy = (n + T - 1) // T
+    x, g = rnd(n * S, d, seed=1), 1 + 0.1 * rnd(d, seed=2)
+    off = torch.randint(0, S, (n,), generator=torch.Generator().manual_seed(3), dtype=torch.int32)
+    dy = q(rnd(ndy, d, seed=4), idt)
+    xr = x.clone().requires_grad_(True)
+    gr = g.clone().requires_grad_(True)
+    br = torch.zeros(d, requires_grad=True)
+    sel = xr.view(n, S, d)[torch.arange(n), off.long()]
+    ref = F.layer_norm(sel, (d,), gr, br, 1e-5)
+    ref.backward(0.5 * dy.repeat_interleave(T, 0)[:n])
+    mean = sel.detach().mean(1)
+    rstd = (sel.detach().var(1, unbiased=False) + 1e-5).rsqrt()
+    dx0 = rnd(n * S, d, seed=5)
+    dx = dev(dx0.clone())
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    ops.layernorm_bwd(dev(dy, idt), dev(x), dev(mean), dev(rstd), dev(g), dx, dg, db, n, d, accumulate=True, dy_div=T, dy_scale=0.5,
+                      in_mul=S, in_off=dev(off))
+    assert rel(dx, dx0 + xr.grad) < 2e-5           # rows that were not gathered keep their running gradient bit for bit
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4     # (4101-term fp32 sums through atomics)
+
+
 # ------------------------------------------------------------------ attention
 def attn_ref(qkv, nseq, L, H, hd, rowidx, causal, key_mask):
     """fp32 reference on gathered rows: returns out rows and a function giving d(qkv) for a cotangent"""
@@ -523,17 +551,22 @@ def test_adam_matches_torch(ops):
 
 
 def test_gemm_tile_kernels_on_the_step_shapes():
-    """Every NT epilogue (bias -> bf16, + fp32 residual, QuickGELU + saved pre-activation, dQuickGELU) on the training step's shapes,
-    once with the default kernel choice and once with the opt-in 256 x 128 two-workgroups-per-CU kernel wherever it is legal
-    (MISSM_GEMM_4W=1, read once per process): tools/gemm_nt_ab.py checks each against fp32 torch."""
+    """Every NT epilogue (bias -> bf16, + fp32 residual, QuickGELU + saved pre-activation, dQuickGELU) on the training step's shapes -
+    the video tower's, configs[4]'s B = 16 shape, one image tower's, and the GROUPED launch of four towers - once with the default
+    kernel choice and once with the opt-in 256 x 128 two-workgroups-per-CU kernel wherever it is legal (MISSM_GEMM_4W=1, read once
+    per process): tools/gemm_nt_ab.py checks EVERY output row of each against fp32 torch (worst element and Frobenius norm).  Then
+    the weight-gradient (TN) kernels on the same shapes, single and grouped: every element of dW, the bias gradient riding along,
+    accumulation and bit-reproducibility (tools/gemm_tn_ab.py)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for knob in ("0", "1"):
-        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_nt_ab.py")], capture_output=True, text=True, timeout=600,
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_nt_ab.py")], capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, MISSM_GEMM_4W=knob), cwd=root)
         assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_tn_ab.py")], capture_output=True, text=True, timeout=900, cwd=root)
+    assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
 
 def test_attention_single_pass_backward():

@@ -33,17 +33,44 @@ def rel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-6))
 
 
-def grad_ok(name, mine, ref, tol, dtype):
+# bf16 instantiation: relative Frobenius error ||g - ref|| / ||ref|| per class of tensor (VERDICT r2 #3b: cos / norm alone pass a
+# gradient that drops 5 % of its rows or mis-scales one head of twelve - each of those is a >= 0.2 Frobenius error).  The bounds
+# are ~2x the largest value measured over every gradient this suite checks (MISSM_GRAD_REPORT=<file> logs them):
+#   matrix    GEMM weight gradients (q/k/v/out/fc1/fc2, patch embedding, projections, fusion linears): bf16 operands, fp32 sums
+#   vector    bias / LayerNorm / class- and temporal-embedding gradients: column sums of bf16-rounded rows
+#   embedding position / token embedding tables
+BF16_FRO = {"matrix": 3e-2, "vector": 5e-2, "embedding": 3e-2}
+
+
+def grad_class(name, t):
+    if "position_embedding" in name or "token_embedding" in name:
+        return "embedding"
+    return "matrix" if t.dim() >= 2 and min(t.shape[0], t.shape[-1]) > 1 else "vector"
+
+
+def fro(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+def grad_ok(name, mine, ref, tol, dtype, fro_scale=1.0):
     """k_proj.bias has an identically-zero gradient (softmax is invariant to a per-query constant), so the reference
     value is rounding noise: compare it on an absolute scale."""
+    import os
     if name.endswith("k_proj.bias"):
         return float((mine.detach().float().cpu() - ref.detach().float().cpu()).abs().max()) < (1e-5 if dtype == torch.float32 else 5e-3)
+    rep = os.environ.get("MISSM_GRAD_REPORT")
+    if rep:
+        with open(rep, "a") as f:
+            f.write(f"{'bf16' if dtype == torch.bfloat16 else 'f32 '} {grad_class(name, ref):9s} fro {fro(mine, ref):.3e} max {rel(mine, ref):.3e} "
+                    f"{tuple(ref.shape)} {name} [{os.environ.get('PYTEST_CURRENT_TEST', '').split('::')[-1]}]\n")
     if dtype == torch.bfloat16:
-        # bf16 operands: gradients that are small sums of cancelling terms (LayerNorm gains over 30 rows) carry a few
-        # percent of rounding noise per element; gate on direction and magnitude instead of the worst element
+        # bf16 operands: direction and magnitude (gradients that are small sums of cancelling terms - LayerNorm gains over 30 rows -
+        # carry a few percent of rounding noise in their worst element) AND the Frobenius bound of the tensor's class
         a, b = mine.detach().float().cpu().flatten(), ref.detach().float().cpu().flatten()
         cos = float(torch.dot(a, b) / (a.norm() * b.norm()).clamp_min(1e-30))
-        return cos > 0.97 and abs(float(a.norm() / b.norm().clamp_min(1e-30)) - 1.0) < 0.1
+        return (cos > 0.97 and abs(float(a.norm() / b.norm().clamp_min(1e-30)) - 1.0) < 0.1
+                and fro(mine, ref) < BF16_FRO[grad_class(name, ref)] * fro_scale)
     return rel(mine, ref) < tol
 
 

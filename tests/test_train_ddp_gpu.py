@@ -207,3 +207,76 @@ def test_student_training_modes_vs_oracle(pkg, mode, tmp_path, monkeypatch):
     model1, *_ = _tiny_model(pkg, torch.float32)
     T.train(args, _batches(2, 6, 100), _batches(2, 6, 100), 5, encoder_model=model1.encoder, compute_dtype=torch.float32, log=lines.append)
     assert len(lines) == 2 and all("val loss" in s for s in lines)
+
+
+def test_optimizer_state_exchanges_with_torch_adam(pkg):
+    """'optimizer_state_dict' is ``torch.optim.Adam.state_dict()``'s layout (reference train_ddp.py:205,303): after two engine
+    steps the state loads into a stock ``optim.Adam(model.parameters())``, whose moments then equal the parameter-shaped slices of the
+    flat moment buffers; a third step taken by torch (autograd gradient mode) and by the engine from that state lands on the same
+    weights; and the state round-trips torch -> engine, by name and by position, surviving a rebind of the towers (``model.to``)."""
+    from missm_benchmark_amd.engine import TrainEngine
+    from missm_benchmark_amd.nn import HipCrossEntropyLoss
+    model, *_ = _tiny_model(pkg, torch.float32)
+    model = model.cuda()
+    (data, label, miss), = _batches(1, 6, 21)
+    d = {m: {k: v.squeeze(1).cuda() for k, v in x.items()} for m, x in data.items()}
+    y, miss = label["label"].cuda(), miss.cuda()
+    crit = HipCrossEntropyLoss()
+
+    def one(engine):
+        engine.zero_grad()
+        crit(model(d, miss), y).backward()
+        engine.step()
+
+    eng = TrainEngine(model, lr=1e-3)
+    one(eng); one(eng)
+    sd = eng.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(list(model.parameters()))))
+    names = [n for n, _ in model.named_parameters()]
+    assert sd["param_groups"][0]["param_names"] == names
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt.load_state_dict(sd)                                   # torch accepts it as its own
+    used = 0
+    for i, p in enumerate(model.parameters()):
+        if i in sd["state"]:
+            assert float(opt.state[p]["step"]) == 2.0 and opt.state[p]["exp_avg"].shape == p.shape
+            used += 1
+    assert used == len(sd["state"]) > 100
+    w0 = {n: p.detach().clone() for n, p in model.named_parameters()}
+    # third step by torch.optim (gradients handed to autograd) ...
+    pkg.towers.set_grad_mode("autograd")
+    try:
+        opt.zero_grad(set_to_none=True)
+        crit(model(d, miss), y).backward()
+        opt.step()
+    finally:
+        pkg.towers.set_grad_mode("direct")
+    w_torch = {n: p.detach().clone() for n, p in model.named_parameters()}
+    after_torch = opt.state_dict()
+    # ... and by the engine from the same state, after the towers were rebound (a device round trip re-allocates the flat buffers)
+    with torch.no_grad():
+        for n, p in model.named_parameters():
+            p.copy_(w0[n])
+    model = model.cpu().cuda()
+    eng2 = TrainEngine(model, lr=5e-4)
+    eng2.load_state_dict(sd)
+    assert eng2.step_count == 2 and eng2.lr == 1e-3
+    one(eng2)
+    for n, p in model.named_parameters():
+        if n.endswith("k_proj.bias"):      # identically-zero gradient: Adam's g / (sqrt(v) + eps) turns its rounding noise into O(lr) steps
+            continue
+        assert rel(p, w_torch[n]) < 2e-5, n
+    # torch's state after its third step, loaded by position (no names) = the engine's own state after its third step
+    plain = {"state": after_torch["state"], "param_groups": [{k: v for k, v in after_torch["param_groups"][0].items() if k != "param_names"}]}
+    eng3 = TrainEngine(model, lr=1e-3)
+    eng3.load_state_dict(plain)
+    a, b = eng3.state_dict(), eng2.state_dict()
+    assert eng3.step_count == 3 and set(a["state"]) == set(b["state"])
+    for i in a["state"]:
+        if names[i].endswith("k_proj.bias"):
+            continue
+        assert rel(a["state"][i]["exp_avg"], b["state"][i]["exp_avg"]) < 1e-4, names[i]
+        assert rel(a["state"][i]["exp_avg_sq"], b["state"][i]["exp_avg_sq"]) < 1e-4, names[i]
+    bad = {"state": {}, "param_groups": [dict(plain["param_groups"][0], params=[0, 1])]}
+    with pytest.raises(ValueError, match="numbers 2 parameters"):
+        eng3.load_state_dict(bad)

@@ -1,13 +1,19 @@
-"""NT GEMM on the hot-path shapes: correctness against torch.matmul (fp32 of the same bf16 operands) and time per launch
-for every epilogue the towers use.  Run once per kernel choice: MISSM_GEMM_8P=0 (16-wave 256x256), 1 (8-phase, staggered),
-2 (8-phase, no stagger); MISSM_GEMM_BIG=0 forces the 128x128 kernel."""
+"""NT GEMM on the hot-path shapes: correctness against torch.matmul (fp32 of the same bf16 operands) on EVERY output row, and
+time per launch, for every epilogue the towers use - single launches and the grouped launch of four shape-identical towers.
+Run once per kernel choice: MISSM_GEMM_8P=0 (16-wave 256x256), 1 (8-phase, staggered), 2 (8-phase, no stagger);
+MISSM_GEMM_BIG=0 forces the 128x128 kernel; MISSM_GEMM_4W=1 the 256x128 two-workgroups-per-CU kernel wherever legal.
+
+Bars (bf16 outputs round to 2^-9 relative, fp32 accumulation): worst element within 1e-2 of the output's scale AND relative
+Frobenius error below 4e-3 (bf16 outputs) / 1e-4 (fp32 outputs), over all rows - the checker walks the rows in 8192-row chunks
+(VERDICT r2 #3a: the first version compared the bottom 300 and the top 256 rows only)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from missm_benchmark_amd import ops
 
-tag = f"8P={os.environ.get('MISSM_GEMM_8P', 'dflt')} BIG={os.environ.get('MISSM_GEMM_BIG', 'dflt')}"
+tag = f"8P={os.environ.get('MISSM_GEMM_8P', 'dflt')} BIG={os.environ.get('MISSM_GEMM_BIG', 'dflt')} 4W={os.environ.get('MISSM_GEMM_4W', 'dflt')}"
 dt = torch.bfloat16
+CHUNK = 8192
 
 
 def timed(fn, iters=10):
@@ -23,16 +29,38 @@ def timed(fn, iters=10):
     return e0.elapsed_time(e1) / iters
 
 
-def check(name, got, ref, tol):
-    err = float((got.float() - ref).abs().max() / ref.abs().max())
-    print(f"      check {name}: rel err {err:.2e} {'OK' if err < tol else 'FAIL'}", flush=True)
-    return err < tol
+def check_all_rows(name, got, ref_fn, tol_max, tol_fro):
+    """got [rows, n] against ref_fn(lo, hi) -> fp32 [hi - lo, n], every row, chunk by chunk"""
+    rows = got.shape[0]
+    emax = rmax = 0.0
+    d2 = r2 = 0.0
+    for lo in range(0, rows, CHUNK):
+        hi = min(rows, lo + CHUNK)
+        ref = ref_fn(lo, hi)
+        d = got[lo:hi].float() - ref
+        emax = max(emax, float(d.abs().max()))
+        rmax = max(rmax, float(ref.abs().max()))
+        d2 += float(d.double().square().sum())
+        r2 += float(ref.double().square().sum())
+    err, fro = emax / rmax, (d2 / max(r2, 1e-300)) ** 0.5
+    good = err < tol_max and fro < tol_fro and bool(torch.isfinite(got).all())
+    print(f"      check {name}: all {rows} rows, worst element {err:.2e} of scale, Frobenius {fro:.2e} {'OK' if good else 'FAIL'}", flush=True)
+    return good
+
+
+def qgelu(r):
+    return r * torch.sigmoid(1.702 * r)
+
+
+def dqgelu(u):
+    sg = torch.sigmoid(1.702 * u)
+    return sg + 1.702 * u * sg * (1 - sg)
 
 
 ok = True
 shapes = [(50432, 2304, 768, "vid qkv"), (50432, 768, 768, "vid out"), (50432, 3072, 768, "vid fc1"), (50432, 768, 3072, "vid fc2"),
-          (50432, 768, 2304, "vid dX qkv"), (25216, 3072, 768, "4img fc1"), (25216, 768, 3072, "4img fc2"), (6304, 3072, 768, "img fc1"),
-          (4096, 4096, 4096, "4096^3")]
+          (50432, 768, 2304, "vid dX qkv"), (25216, 3072, 768, "4img fc1"), (25216, 768, 3072, "4img fc2"), (25216, 768, 768, "b16 vid out"),
+          (6304, 3072, 768, "img fc1"), (6304, 768, 768, "img out"), (4096, 4096, 4096, "4096^3")]
 if len(sys.argv) > 1:
     shapes = [s for s in shapes if any(a in s[3] for a in sys.argv[1:])]
 for rows, n, k, nm in shapes:
@@ -40,36 +68,72 @@ for rows, n, k, nm in shapes:
     x = torch.randn(rows, k, device="cuda", generator=g).to(dt)
     w = (torch.randn(n, k, device="cuda", generator=g) * 0.05).to(dt)
     bias = torch.randn(n, device="cuda", generator=g)
+    wf = w.float()
+    lin = lambda lo, hi: x[lo:hi].float() @ wf.t()            # noqa: E731
     fl = 2.0 * rows * n * k
     # (1) plain bf16 out + bias
     y = torch.empty(rows, n, device="cuda", dtype=dt)
     ms = timed(lambda: ops.gemm(x, w, y, bias=bias))
     print(f"[{tag}] {nm:12s} [{rows}x{n}x{k}] bias->bf16      {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
-    sl = slice(rows - 300, rows)      # the ragged bottom rows and a stripe of every column tile
-    ref = x[sl].float() @ w.float().t() + bias
-    ok &= check("bias", y[sl], ref, 1e-2)
-    ref0 = x[:256].float() @ w.float().t() + bias
-    ok &= check("bias(top)", y[:256], ref0, 1e-2)
+    ok &= check_all_rows("bias", y, lambda lo, hi: lin(lo, hi) + bias, 1e-2, 4e-3)
     # (2) fp32 out + bias + residual (out_proj / fc2)
     if n <= 768:
         res = torch.randn(rows, n, device="cuda", generator=g)
         y32 = torch.empty(rows, n, device="cuda")
         ms = timed(lambda: ops.gemm(x, w, y32, bias=bias, resid=res))
         print(f"[{tag}] {nm:12s} [{rows}x{n}x{k}] bias+resid->f32 {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
-        ok &= check("resid", y32[sl], ref + res[sl], 2e-3)
+        ok &= check_all_rows("resid", y32, lambda lo, hi: lin(lo, hi) + bias + res[lo:hi], 2e-3, 1e-4)
+        del res, y32
     # (3) quick_gelu with the saved pre-activation (fc1) and its backward epilogue (dX of fc2)
     if n == 3072:
         a = torch.empty(rows, n, device="cuda", dtype=dt)
         u = torch.empty(rows, n, device="cuda", dtype=dt)
         ms = timed(lambda: ops.gemm(x, w, a, bias=bias, act=ops.ACT_QGELU, aux_out=u))
         print(f"[{tag}] {nm:12s} [{rows}x{n}x{k}] bias+qgelu+u    {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
-        ok &= check("u", u[sl], ref, 1e-2)
-        ok &= check("qgelu", a[sl], ref * torch.sigmoid(1.702 * ref), 1e-2)
+        ok &= check_all_rows("u", u, lambda lo, hi: lin(lo, hi) + bias, 1e-2, 4e-3)
+        ok &= check_all_rows("qgelu", a, lambda lo, hi: qgelu(lin(lo, hi) + bias), 1e-2, 4e-3)
         du = torch.empty(rows, n, device="cuda", dtype=dt)
         ms = timed(lambda: ops.gemm(x, w, du, act=ops.ACT_DQGELU, aux_in=u))
         print(f"[{tag}] {nm:12s} [{rows}x{n}x{k}] dqgelu(u)       {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
-        uf = u[sl].float()
-        sg = torch.sigmoid(1.702 * uf)
-        ok &= check("dqgelu", du[sl], (x[sl].float() @ w.float().t()) * (sg + 1.702 * uf * sg * (1 - sg)), 1e-2)
-    del x, w, y
+        ok &= check_all_rows("dqgelu", du, lambda lo, hi: lin(lo, hi) * dqgelu(u[lo:hi].float()), 1e-2, 4e-3)
+        del a, u, du
+    del x, w, y, wf
+
+# ---- grouped launches: the same linear of four shape-identical towers (6304 rows each) in ONE call, every epilogue
+gshapes = [(6304, 2304, 768, "4x img qkv"), (6304, 768, 768, "4x img out"), (6304, 3072, 768, "4x img fc1"), (6304, 768, 3072, "4x img fc2")]
+if len(sys.argv) > 1:
+    gshapes = [s for s in gshapes if any(a in s[3] for a in sys.argv[1:])]
+G = 4
+for rows, n, k, nm in gshapes:
+    g = torch.Generator(device="cuda").manual_seed(5)
+    xs = [torch.randn(rows, k, device="cuda", generator=g).to(dt) for _ in range(G)]
+    ws = [(torch.randn(n, k, device="cuda", generator=g) * 0.05).to(dt) for _ in range(G)]
+    bs = [torch.randn(n, device="cuda", generator=g) for _ in range(G)]
+    fl = 2.0 * rows * n * k * G
+    lin = lambda i: (lambda lo, hi: xs[i][lo:hi].float() @ ws[i].float().t() + bs[i])      # noqa: E731
+    ys = [torch.empty(rows, n, device="cuda", dtype=dt) for _ in range(G)]
+    ms = timed(lambda: ops.gemm_grouped(xs, ws, ys, bias=bs))
+    print(f"[{tag}] {nm:12s} [{G}x {rows}x{n}x{k}] bias->bf16      {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
+    for i in range(G):
+        ok &= check_all_rows(f"group {i} bias", ys[i], lin(i), 1e-2, 4e-3)
+    if n <= 768:
+        rs = [torch.randn(rows, n, device="cuda", generator=g) for _ in range(G)]
+        y32 = [torch.empty(rows, n, device="cuda") for _ in range(G)]
+        ms = timed(lambda: ops.gemm_grouped(xs, ws, y32, bias=bs, resid=rs))
+        print(f"[{tag}] {nm:12s} [{G}x {rows}x{n}x{k}] bias+resid->f32 {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
+        for i in range(G):
+            ok &= check_all_rows(f"group {i} resid", y32[i], (lambda i: lambda lo, hi: lin(i)(lo, hi) + rs[i][lo:hi])(i), 2e-3, 1e-4)
+    if n == 3072:
+        as_ = [torch.empty(rows, n, device="cuda", dtype=dt) for _ in range(G)]
+        us = [torch.empty(rows, n, device="cuda", dtype=dt) for _ in range(G)]
+        ms = timed(lambda: ops.gemm_grouped(xs, ws, as_, bias=bs, act=ops.ACT_QGELU, aux_out=us))
+        print(f"[{tag}] {nm:12s} [{G}x {rows}x{n}x{k}] bias+qgelu+u    {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
+        dus = [torch.empty(rows, n, device="cuda", dtype=dt) for _ in range(G)]
+        ms = timed(lambda: ops.gemm_grouped(xs, ws, dus, act=ops.ACT_DQGELU, aux_in=us))
+        print(f"[{tag}] {nm:12s} [{G}x {rows}x{n}x{k}] dqgelu(u)       {ms*1e3:8.1f} us {fl/ms/1e9:7.1f} TFLOP/s", flush=True)
+        for i in range(G):
+            ok &= check_all_rows(f"group {i} u", us[i], lin(i), 1e-2, 4e-3)
+            ok &= check_all_rows(f"group {i} qgelu", as_[i], (lambda i: lambda lo, hi: qgelu(lin(i)(lo, hi)))(i), 1e-2, 4e-3)
+            ok &= check_all_rows(f"group {i} dqgelu", dus[i],
+                                 (lambda i: lambda lo, hi: (xs[i][lo:hi].float() @ ws[i].float().t()) * dqgelu(us[i][lo:hi].float()))(i), 1e-2, 4e-3)
 print("ALL OK" if ok else "SOME CHECKS FAILED")
