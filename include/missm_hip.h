@@ -220,6 +220,16 @@ int missm_adam_step(float* p, const float* g, float* m, float* v, long n, int st
 int missm_adam_cast_batched(const void* tiles, int ntiles, long g_off, long m_off, long v_off, int step, float lr, float beta1,
                             float beta2, float eps, float weight_decay, float grad_scale, int dtype, void* stream);
 
+/* LoRA adapters of the vision encoders (languagebind/image/modeling_image.py:775-793: peft's get_peft_model over vision_model.encoder,
+ * targets q/k/v/out_proj - or temporal_attn.* and temporal_mlp.fc1/fc2 with add_time_attn; lora_dropout 0, configuration_image.py:200-202).
+ * merge: W[n_out, k_in] (fp32, leading dimension ldw) += scale * B[n_out, r] A[r, k_in] - the weight the unmerged peft forward
+ * x W^T + scale (x A^T) B^T is the linear of (scale = lora_alpha / r); the compute-dtype weight copies are cast from it.
+ * grad : dB[n_out, r] += scale * G A^T, dA[r, k_in] += scale * B^T G from the full weight gradient G = dY^T X [n_out, k_in] that the
+ * weight-gradient GEMM produces; base weights stay frozen (adapter-only training, as in the reference). */
+int missm_lora_merge(float* W, int ldw, const float* A, const float* B, int n_out, int k_in, int r, float scale, void* stream);
+int missm_lora_grad(const float* G, int ldg, const float* A, const float* B, float* dA, float* dB, int n_out, int k_in, int r, float scale,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

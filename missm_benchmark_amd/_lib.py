@@ -52,11 +52,13 @@ SIGNATURES = {
     "missm_dropout_bwd": [P, P, P, L, F, P],
     "missm_adam_step": [P, P, P, P, L, I, F, F, F, F, F, F, P],
     "missm_adam_cast_batched": [P, I, L, L, L, I, F, F, F, F, F, F, I, P],
+    "missm_lora_merge": [P, I, P, P, I, I, I, F, P],
+    "missm_lora_grad": [P, I, P, P, P, P, I, I, I, F, P],
 }
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
 
-ABI_VERSION = 7     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 8     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

@@ -84,6 +84,10 @@ class TrainEngine:
                 frozen_towers.append(m)      # a frozen tower (e.g. a distillation teacher's encoder) is simply not optimised
             elif flags == {True}:
                 self.towers.append(m)
+            elif m.lora and all(p.requires_grad == m.is_trainable(n) for n, p in zip(m._param_names, m._plist)):
+                # LoRA tower (image/modeling_image.py:775-793): frozen encoder, trainable adapters + embeddings + outer LayerNorms -
+                # the one sanctioned mix; optimizer and all-reduce touch only tower.trainable_ranges()
+                self.towers.append(m)
             else:
                 # the optimizer and the all-reduce address a tower as ONE flat buffer: per-parameter freezing inside a tower
                 # would still be updated (weight decay / stale Adam moments) - refuse instead of doing that silently
@@ -112,8 +116,9 @@ class TrainEngine:
         self.update_stream = (self.comm_stream if self.world > 1 else torch.cuda.Stream()) if (eager_step and torch.cuda.is_available()) else None
         self._bucket_updated = {}            # id(tower) -> [flat ranges already updated during this backward]
         for t in self.towers:
-            t._post_backward = self._tower_done if (self.world > 1 or eager_step) else None
-            t._bucket_hook = self._bucket_ready if (self.overlap or eager_step) else None
+            # (LoRA towers: two small trainable ranges - reduced and updated in step(), nothing rides inside the backward)
+            t._post_backward = self._tower_done if ((self.world > 1 or eager_step) and not t.lora) else None
+            t._bucket_hook = self._bucket_ready if ((self.overlap or eager_step) and not t.lora) else None
         if self.world > 1:
             self.broadcast_parameters()
 
@@ -223,9 +228,13 @@ class TrainEngine:
     def reduce_gradients(self):
         """finish the gradient exchange: all-reduce (SUM) what is still local and wait for the overlapped reductions"""
         if self.world > 1:
+            for t in self.towers:
+                if t.lora and t._grad_fresh:
+                    for lo, hi in t.trainable_ranges():
+                        self._all_reduce_async(t.flat_grad()[lo:hi])
             if not self.overlap:
                 for _, g, t in self.flat_buffers():
-                    if t is not None and t._grad_fresh:
+                    if t is not None and t._grad_fresh and not t.lora:
                         self._all_reduce_async(g)
             if self.rest is not None:
                 self.rest.reattach()
@@ -268,6 +277,14 @@ class TrainEngine:
             raise RuntimeError("TrainEngine.apply_adam: parameters are not on a GPU (no CPU optimizer path)")
         m, v = self._moments(master, t)
         hp = (self.step_count + 1, self.lr, self.betas[0], self.betas[1], self.eps, self.wd)
+        if t is not None and t.lora:
+            # adapter-only training: Adam on the trainable ranges; the frozen encoder (and its gradient scratch) is never touched;
+            # the merged GEMM weights W + (alpha / r) B A are rebuilt before the next forward (ClipTower._refresh_shadows)
+            for lo, hi in t.trainable_ranges():
+                ops.adam_step(master[lo:hi], grad[lo:hi], m[lo:hi], v[lo:hi], *hp, grad_scale=1.0 / self.world)
+            t.mark_dirty()
+            t._grad_fresh = False
+            return
         if flat_range is not None:
             # one gradient bucket of a tower: the weight matrices that start inside it, and - if it is the tail range (it ends
             # with the flat buffer) - the vector parameters behind the matrices
@@ -334,7 +351,7 @@ class TrainEngine:
         state, names = {}, []
         for i, (name, p, where) in enumerate(self._located_params()):
             names.append(name)
-            if where is None:
+            if where is None or not p.requires_grad:     # (frozen parameters have no optimizer state, as in torch)
                 continue
             mv = self._state.get(where[0])
             if mv is None or self.step_count == 0:
@@ -389,7 +406,7 @@ class TrainEngine:
         steps = set()
         for (name, p, where), idx in zip(located, pick):
             st = sd["state"].get(idx) if idx is not None else None
-            if st is None or where is None:
+            if st is None or where is None or not p.requires_grad:
                 continue
             if tuple(st["exp_avg"].shape) != tuple(p.shape):
                 raise ValueError(f"optimizer state of {name}: shape {tuple(st['exp_avg'].shape)} vs parameter {tuple(p.shape)}")

@@ -100,9 +100,11 @@ def resize_pos_embed(weight: torch.Tensor, grid, extra_tokens: int = 1) -> torch
     return torch.cat([tok.float(), img], dim=0).to(weight.dtype)
 
 
-def _vision_config_from_json(raw: dict) -> TowerConfig:
+def _vision_config_from_json(raw: dict, modality: str = "image") -> TowerConfig:
     fields = TowerConfig.__dataclass_fields__
     kw = {k: v for k, v in raw.items() if k in fields and k != "kind"}
+    if modality != "video" and kw.get("add_time_attn"):
+        kw["temporal_mlp"] = True       # the image-family layer keeps the time branch's MLP (image/modeling_image.py:83-84), the video file dropped it
     if raw.get("num_mel_bins", 0) and raw.get("target_length", 0):      # audio (image/modeling_image.py:797-798): spectrogram image
         kw["image_size"] = (int(raw["num_mel_bins"]), int(raw["target_length"]))
     elif isinstance(kw.get("image_size"), list):
@@ -149,11 +151,14 @@ class LanguageBindModel(nn.Module):
 
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path: str, cache_dir: Optional[str] = None, *, allow_synthetic: bool = False,
-                        **kw):
+                        merge_lora: bool = False, **kw):
         """A directory with ``config.json`` and ``pytorch_model.bin`` / ``model.pt`` / ``model.pth`` (see
         ``resolve_checkpoint_dir``).  Like the reference (languagebind/__init__.py:63-64) this FAILS when the checkpoint
         cannot be found or is incomplete; a seeded synthetic model is built only on request (``allow_synthetic=True``, or
-        ``LanguageBind(configs=...)``)."""
+        ``LanguageBind(configs=...)``).
+        A peft-wrapped checkpoint (``vision_config.lora_r`` > 0, adapter keys in the state dict) loads as the reference builds it
+        (image/modeling_image.py:775-793): frozen encoder + trainable rank-r adapters, fine-tuned adapter-only.  ``merge_lora=True``
+        folds the adapters into plain weights instead (full fine-tuning of the merged model, the round-2 behaviour)."""
         root = cls.resolve_checkpoint_dir(pretrained_model_name_or_path, cache_dir)
         if root is None:
             if allow_synthetic:
@@ -163,18 +168,25 @@ class LanguageBindModel(nn.Module):
                                     "LanguageBind(configs=...) or allow_synthetic=True for seeded random towers")
         raw = json.load(open(os.path.join(root, "config.json")))
         fields = TowerConfig.__dataclass_fields__
-        vc = _vision_config_from_json(raw.get("vision_config", {}))
-        tc = TowerConfig(kind="text", **{k: v for k, v in raw.get("text_config", {}).items() if k in fields and k != "kind"})
-        kw.pop("text_config", None)
-        kw.pop("projection_dim", None)
-        model = cls(vc, tc, raw.get("projection_dim", PROJECTION_DIM), raw.get("logit_scale_init_value", LOGIT_SCALE_INIT), **kw)
         files = [os.path.join(root, fn) for fn in ("pytorch_model.bin", "model.pt", "model.pth") if os.path.exists(os.path.join(root, fn))]
         if not files:
             raise FileNotFoundError(f"{root} holds a config.json but no pytorch_model.bin / model.pt / model.pth")
         sd = torch.load(files[0], map_location="cpu")
+        vraw = dict(raw.get("vision_config", {}))
         if any(".lora_A." in k for k in sd):
-            vraw = raw.get("vision_config", {})
-            sd = merge_lora_state_dict(sd, int(vraw.get("lora_r", 2)), float(vraw.get("lora_alpha", 16)))
+            if merge_lora:
+                sd = merge_lora_state_dict(sd, int(vraw.get("lora_r", 2)), float(vraw.get("lora_alpha", 16)))
+                vraw["lora_r"] = 0
+            else:
+                vraw.setdefault("lora_r", 2)       # configuration_image.py:200-201 defaults
+                vraw.setdefault("lora_alpha", 16)
+        else:
+            vraw["lora_r"] = 0                  # plain weights: nothing was wrapped when this checkpoint was written
+        vc = _vision_config_from_json(vraw, cls.modality)
+        tc = TowerConfig(kind="text", **{k: v for k, v in raw.get("text_config", {}).items() if k in fields and k != "kind"})
+        kw.pop("text_config", None)
+        kw.pop("projection_dim", None)
+        model = cls(vc, tc, raw.get("projection_dim", PROJECTION_DIM), raw.get("logit_scale_init_value", LOGIT_SCALE_INIT), **kw)
         sd = {k: v for k, v in sd.items() if not k.endswith("position_ids")}     # non-persistent buffers in newer layouts
         pk = "vision_model.embeddings.position_embedding.weight"
         if pk in sd and sd[pk].shape[0] != vc.seq_len:                         # a checkpoint trained on another patch grid

@@ -475,3 +475,22 @@ def adam_cast_batched(table, ntiles, master, g, m, v, step, lr, beta1, beta2, ep
 def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.0, grad_scale=1.0):
     _lib.call("missm_adam_step", p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel(), int(step), float(lr),
               float(beta1), float(beta2), float(eps), float(weight_decay), float(grad_scale), _s())
+
+
+def lora_merge(w, a, b, scale):
+    """w[n_out, k_in] (fp32 view, unit inner stride) += scale * b[n_out, r] @ a[r, k_in]  (peft's merged weight, see include/missm_hip.h)"""
+    n, k = w.shape
+    r = a.shape[0]
+    if a.shape != (r, k) or b.shape != (n, r) or w.stride(1) != 1 or not a.is_contiguous() or not b.is_contiguous() or w.dtype != torch.float32:
+        raise _lib.MissmError("lora_merge: w [n, k], a [r, k], b [n, r] (fp32, contiguous rows)")
+    _lib.call("missm_lora_merge", w.data_ptr(), w.stride(0), a.data_ptr(), b.data_ptr(), n, k, r, float(scale), _s())
+
+
+def lora_grad(g, a, b, da, db, scale):
+    """da[r, k_in] += scale * b^T g ; db[n_out, r] += scale * g a^T  from the full weight gradient g[n_out, k_in]"""
+    n, k = g.shape
+    r = a.shape[0]
+    if a.shape != (r, k) or b.shape != (n, r) or da.shape != a.shape or db.shape != b.shape or g.stride(1) != 1 or g.dtype != torch.float32 or \
+            not (a.is_contiguous() and b.is_contiguous() and da.is_contiguous() and db.is_contiguous()):
+        raise _lib.MissmError("lora_grad: g [n, k], a / da [r, k], b / db [n, r] (fp32, contiguous rows)")
+    _lib.call("missm_lora_grad", g.data_ptr(), g.stride(0), a.data_ptr(), b.data_ptr(), da.data_ptr(), db.data_ptr(), n, k, r, float(scale), _s())

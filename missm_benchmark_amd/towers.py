@@ -48,7 +48,11 @@ class TowerConfig:
     add_time_attn: bool = False
     num_frames: int = 1
     temporal_mlp: bool = False
-    force_patch_dropout: float = 0.0     # PatchDropout (image/modeling_image.py:30-63): identity at 0 / in eval; > 0 is rejected
+    force_patch_dropout: float = 0.0     # PatchDropout (image/modeling_image.py:30-63): identity at 0 / in eval; in training a random subset of the patch tokens
+    # LoRA adapters over the vision encoder (configuration_image.py:200-202, image/modeling_image.py:775-793); 0 = plain weights
+    lora_r: int = 0
+    lora_alpha: float = 16.0
+    lora_dropout: float = 0.0
     # text (configuration_image.py:70-105)
     vocab_size: int = 49408
     max_position_embeddings: int = 77
@@ -73,14 +77,34 @@ def _r64(n: int) -> int:
     return (n + 63) // 64 * 64
 
 
+class PatchDropout:
+    """``PatchDropout`` of the reference (image/modeling_image.py:19-63, https://arxiv.org/abs/2212.00794): in training, with
+    probability parameter ``prob`` > 0, every sample keeps its class token and ``max(1, int(num_tokens * (1 - prob)))`` patch tokens
+    chosen by ``torch.randn(batch, num_tokens).topk(k)`` ON THE CPU with torch's global generator (T > 1: one draw per sample,
+    shared by its frames).  ``keep_indices`` makes exactly that draw, so a run seeded like the reference drops the same tokens; a
+    caller can also hand the indices in (``tower(pixel_values, patch_keep=idx)``) - which is how the parity tests pin the choice."""
+
+    def __init__(self, prob: float, exclude_first_token: bool = True):
+        assert 0 <= prob < 1.0
+        self.prob = prob
+        self.exclude_first_token = exclude_first_token
+
+    def num_keep(self, num_tokens: int) -> int:
+        return max(1, int(num_tokens * (1 - self.prob)))
+
+    def keep_indices(self, B: int, T: int, num_tokens: int) -> torch.Tensor:
+        rand = torch.randn(B * T if T == 1 else B, num_tokens)
+        return rand.topk(self.num_keep(num_tokens), dim=-1).indices
+
+
 class ClipTower(nn.Module):
     def __init__(self, config: TowerConfig, compute_dtype: torch.dtype = torch.bfloat16, seed: Optional[int] = None):
         super().__init__()
         c = config
         if c.hidden_act not in ops.ACT_CODE:
             raise ValueError(f"unsupported hidden_act {c.hidden_act!r}")
-        if c.temporal_mlp:
-            raise NotImplementedError("temporal_mlp (image-family add_time_attn branch) is not on the HIP path yet")
+        if c.temporal_mlp and not c.add_time_attn:
+            raise ValueError("temporal_mlp is the MLP of the time branch: it needs add_time_attn=True (image/modeling_image.py:73-84)")
         if c.hidden_size % c.num_attention_heads or (c.hidden_size // c.num_attention_heads) % 8:
             raise ValueError("head_dim must be a multiple of 8")
         if c.kind == "vision" and (c.image_hw[0] % c.patch_size or c.image_hw[1] % c.patch_size or c.image_hw[1] % 4):
@@ -89,11 +113,18 @@ class ClipTower(nn.Module):
             raise NotImplementedError(f"{c.seq_len} tokens per sequence need head_dim 64 (the key-chunked attention kernels)")
         if c.kind != "vision" and c.seq_len > 256:
             raise NotImplementedError("causal attention over more than 256 tokens is not instantiated")
-        if c.kind == "vision" and c.force_patch_dropout:
-            raise NotImplementedError("force_patch_dropout > 0 (random token dropping in training, image/modeling_image.py:30-63) is not "
-                                      "implemented; the default configuration uses 0")
+        if not 0.0 <= c.force_patch_dropout < 1.0:
+            raise ValueError("force_patch_dropout must be in [0, 1)")        # the reference's assert, image/modeling_image.py:26
+        # LoRA (image/modeling_image.py:775-793): peft wraps vision_model.encoder - every encoder parameter is frozen, the target
+        # linears get trainable rank-r adapters A [r, in] / B [out, r]; embeddings, pre_layrnorm and post_layernorm (outside the
+        # encoder) stay trainable.  The text tower is never wrapped.
+        self.lora = c.kind == "vision" and c.lora_r > 0
+        if self.lora and c.lora_dropout > 0:
+            raise NotImplementedError("lora_dropout > 0: the adapters ride in the merged GEMM weight W + (alpha / r) B A, which is the "
+                                      "unmerged forward only without dropout on the adapter input (the reference default is 0.0)")
         self.config = c
         self.compute_dtype = compute_dtype
+        self.patch_dropout = PatchDropout(c.force_patch_dropout)
         d, f = c.hidden_size, c.intermediate_size
         blocks: List[Block] = []
         patch_block = None
@@ -119,6 +150,12 @@ class ClipTower(nn.Module):
                 self._mat_blocks[f"{p}.tqkv"] = b
                 b = Block([(f"{p}.temporal_attn.out_proj.weight", (d, d))], "mat"); blocks.append(b)
                 self._mat_blocks[f"{p}.tout"] = b
+                if c.temporal_mlp:       # image-family time branch (image/modeling_image.py:83-84,129-134); the video file removed it
+                    for key, name, shape in (("tfc1", "temporal_mlp.fc1.weight", (f, d)), ("tfc2", "temporal_mlp.fc2.weight", (d, f))):
+                        b = Block([(f"{p}.{name}", shape)], "mat"); blocks.append(b)
+                        self._mat_blocks[f"{p}.{key}"] = b
+                    vec += [(f"{p}.temporal_mlp.fc1.bias", (f,)), (f"{p}.temporal_mlp.fc2.bias", (d,)),
+                            (f"{p}.temporal_layer_norm2.weight", (d,)), (f"{p}.temporal_layer_norm2.bias", (d,))]
                 vec += [(f"{p}.temporal_embedding", (1, c.num_frames, d))]
                 vec += [(f"{p}.temporal_attn.{n}_proj.bias", (d,)) for n in "qkv"]
                 vec += [(f"{p}.temporal_attn.out_proj.bias", (d,)), (f"{p}.temporal_layer_norm1.weight", (d,)),
@@ -135,22 +172,47 @@ class ClipTower(nn.Module):
                     (f"{p}.layer_norm2.bias", (d,))]
             blocks.append(Block(vec, "vec"))
         tail = "post_layernorm" if c.kind == "vision" else "final_layer_norm"
-        blocks.append(Block([(f"{tail}.weight", (d,)), (f"{tail}.bias", (d,))], "vec"))
+        tail_block = Block([(f"{tail}.weight", (d,)), (f"{tail}.bias", (d,))], "vec")
+        blocks.append(tail_block)
+        # LoRA sites: (mat-block key, first row inside the block's [rows, k_in] matrix, n_out, k_in, internal stem of the linear).
+        # Targets (:778-783): q/k/v/out_proj of self_attn - or, with add_time_attn, of temporal_attn plus temporal_mlp.fc1 / fc2
+        # (the video file names the MLP it removed; peft skips names that match nothing).
+        self._lora_sites = []
+        if self.lora:
+            for i in range(c.num_hidden_layers):
+                p = f"encoder.layers.{i}"
+                attn, qkv_key, out_key = ("temporal_attn", "tqkv", "tout") if c.add_time_attn else ("self_attn", "qkv", "out")
+                for j, n in enumerate("qkv"):
+                    self._lora_sites.append((f"{p}.{qkv_key}", j * d, d, d, f"{p}.{attn}.{n}_proj"))
+                self._lora_sites.append((f"{p}.{out_key}", 0, d, d, f"{p}.{attn}.out_proj"))
+                if c.add_time_attn and c.temporal_mlp:
+                    self._lora_sites.append((f"{p}.tfc1", 0, f, d, f"{p}.temporal_mlp.fc1"))
+                    self._lora_sites.append((f"{p}.tfc2", 0, d, f, f"{p}.temporal_mlp.fc2"))
+            for _, _, n_out, k_in, stem in self._lora_sites:     # one 256-byte aligned block per adapter pair, behind the tail LayerNorm
+                blocks.append(Block([(f"{stem}.lora_A.default.weight", (c.lora_r, k_in)), (f"{stem}.lora_B.default.weight", (n_out, c.lora_r))], "vec"))
         if patch_block is not None:
             blocks.append(patch_block)
             self._mat_blocks["patch"] = patch_block
         self._store = FlatStore(blocks)
+        self._lora_stems = {site[4] for site in self._lora_sites}
+        self._merged = None
+        if self.lora:
+            # trainable flat ranges: [patch matrix | embeddings + pre_layrnorm] and [post_layernorm | adapters]; between them lie the
+            # frozen encoder vectors, in front of them the frozen encoder matrices (whose gradient slots are scratch for dW)
+            first_layer_vec = next(b for b in self._store.blocks if b.kind == "vec" and b.items[0][0].startswith("encoder.layers."))
+            self._trainable = [(patch_block.offset, first_layer_vec.offset), (tail_block.offset, self._store.total)]
         # gradient buckets (engine.TrainEngine, N > 1 GPUs): flat ranges that become final as the backward walks the layers
         # 11 -> 0; `bucket_layers` consecutive layers per message, then [patch embedding | all vector parameters] at the end
         self.bucket_layers = 3
         self._bucket_hook = None
         self._param_names = list(self._store.index.keys())
+        self._pub = {n: self._public_name(n) for n in self._param_names}     # internal (flat-store) name -> state-dict key
         for name in self._param_names:
-            attach(self, name, nn.Parameter(self._store.view(name)))
+            attach(self, self._pub[name], nn.Parameter(self._store.view(name), requires_grad=self.is_trainable(name)))
         n_pos = c.seq_len
         self.embeddings.register_buffer("position_ids", torch.arange(n_pos).expand((1, -1)).clone(), persistent=False)
         self._anchor = torch.zeros((), requires_grad=True)
-        self._plist = [self.get_parameter(n) for n in self._param_names]
+        self._plist = [self._param(n) for n in self._param_names]
         self._shadow = {}
         self._shadow_version = None
         # load_state_dict writes through the parameters: belt and braces next to the version key below
@@ -166,6 +228,29 @@ class ClipTower(nn.Module):
     def named_flat(self):
         return self._store
 
+    def _public_name(self, name: str) -> str:
+        """state-dict key of an internal parameter name.  Plain towers: the same.  LoRA towers carry peft's wrapper names
+        (image/modeling_image.py:793 replaces vision_model.encoder by get_peft_model(...)): ``encoder.layers.N.x`` becomes
+        ``encoder.base_model.model.layers.N.x``, and a wrapped linear's own weight / bias move under ``.base_layer``."""
+        if not self.lora or not name.startswith("encoder.layers."):
+            return name
+        stem, leaf = name.rsplit(".", 1)
+        rest = name[len("encoder."):]
+        if stem in self._lora_stems:
+            rest = stem[len("encoder."):] + ".base_layer." + leaf
+        return "encoder.base_model.model." + rest
+
+    def is_trainable(self, name: str) -> bool:
+        """LoRA towers: inside the encoder only the adapters train (peft freezes everything else it wraps)"""
+        return not self.lora or not name.startswith("encoder.layers.") or ".lora_" in name
+
+    def _param(self, name: str) -> nn.Parameter:
+        return self.get_parameter(self._pub[name])
+
+    def trainable_ranges(self):
+        """flat ranges the optimizer and the all-reduce touch: everything, or (LoRA) the two ranges around the frozen encoder"""
+        return list(self._trainable) if self.lora else [(0, self._store.total)]
+
     @torch.no_grad()
     def reset_parameters(self, seed: int):
         """Seeded init with the std's of CLIPPreTrainedModel._init_weights (image/modeling_image.py:179-230)."""
@@ -177,7 +262,11 @@ class ClipTower(nn.Module):
         for name in self._param_names:
             shape = self._store.index[name][1]
             leaf = name.split(".")[-2] + "." + name.split(".")[-1] if "." in name else name
-            if name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight"):
+            if ".lora_A." in name:          # peft's default: kaiming_uniform(a = sqrt(5)) = U(-1/sqrt(in), 1/sqrt(in)); B = 0
+                t = (torch.rand(shape, generator=g) * 2 - 1) * shape[1] ** -0.5
+            elif ".lora_B." in name:
+                t = torch.zeros(shape)
+            elif name.endswith("norm.weight") or name.endswith("norm1.weight") or name.endswith("norm2.weight"):
                 t = torch.ones(shape)
             elif name.endswith(".bias"):
                 t = torch.zeros(shape)
@@ -200,10 +289,11 @@ class ClipTower(nn.Module):
 
     def _rebind(self):
         for name in self._param_names:
-            p = self.get_parameter(name)
+            p = self._param(name)
             p.data = self._store.view(name)
             p.grad = None
-        self._plist = [self.get_parameter(n) for n in self._param_names]
+        self._plist = [self._param(n) for n in self._param_names]
+        self._merged = None
         self._grad_cache = None
         self._grad_fresh = False
         self._shadow.clear()
@@ -251,13 +341,27 @@ class ClipTower(nn.Module):
         """(re)build the compute-dtype copies W [N,K] and W^T [K,N] of every GEMM weight block - one launch per tower"""
         st = self._store
         T = self.compute_dtype
+        base = st.master
+        if self.lora:
+            # the GEMMs read W' = W + (alpha / r) B A (csrc/lora.hip): a second fp32 image of the matrix range, rebuilt from the frozen
+            # base weights and the current adapters whenever either changed (once per optimizer step)
+            if self._merged is None or self._merged.device != st.master.device:
+                self._merged = torch.empty(st.vec_start, device=st.master.device, dtype=torch.float32)
+                self._shadow.clear()
+            self._merged.copy_(st.master[:st.vec_start])
+            scale = float(self.config.lora_alpha) / float(self.config.lora_r)
+            for key, row0, n_out, k_in, stem in self._lora_sites:
+                b = self._mat_blocks[key]
+                w = self._merged[b.offset:b.offset + b.numel].view(-1, k_in)[row0:row0 + n_out]
+                ops.lora_merge(w, st.view(f"{stem}.lora_A.default.weight"), st.view(f"{stem}.lora_B.default.weight"), scale)
+            base = self._merged
         if not self._shadow:
             entries = []
             self._cast_tile_range = []          # (flat offset of the block, first tile, tile count) in table order
             for key, b in self._mat_blocks.items():
                 n_out = sum(it[1][0] for it in b.items)
                 k_in = b.numel // n_out
-                src = st.block_view(b, st.master).view(n_out, k_in)
+                src = st.block_view(b, base).view(n_out, k_in)
                 w = src if T == torch.float32 else torch.empty(n_out, k_in, device=src.device, dtype=T)
                 wt = torch.empty(k_in, n_out, device=src.device, dtype=T)
                 self._shadow[key] = (w, wt)
@@ -276,7 +380,7 @@ class ClipTower(nn.Module):
     def fused_update_ready(self) -> bool:
         """shadows exist and are current: the weight matrices may be updated through the cast-tile table"""
         st = self._store
-        return bool(self._shadow) and st.master.is_cuda and self._shadow_version == self._version_key()
+        return not self.lora and bool(self._shadow) and st.master.is_cuda and self._shadow_version == self._version_key()
 
     def adam_and_refresh(self, grad, m, v, step, lr, beta1, beta2, eps, weight_decay, grad_scale=1.0, flat_range=None):
         """``flat_range`` = (lo, hi): only the weight matrices whose blocks start inside that range of the flat buffer (one
@@ -331,10 +435,25 @@ class ClipTower(nn.Module):
                     setattr(L, nm, st.view(f"{p}.{key}")); setattr(L, "g_" + nm, st.gview(f"{p}.{key}"))
                 L.temb = st.view(f"{p}.temporal_embedding").view(c.num_frames, d)
                 L.g_temb = st.gview(f"{p}.temporal_embedding").view(c.num_frames, d)
-                for key in ("tqkv", "tout"):
+                if c.temporal_mlp:
+                    for nm, key in (("tfc1_b", "temporal_mlp.fc1.bias"), ("tfc2_b", "temporal_mlp.fc2.bias"),
+                                    ("tln2_w", "temporal_layer_norm2.weight"), ("tln2_b", "temporal_layer_norm2.bias")):
+                        setattr(L, nm, st.view(f"{p}.{key}")); setattr(L, "g_" + nm, st.gview(f"{p}.{key}"))
+                for key in ("tqkv", "tout") + (("tfc1", "tfc2") if c.temporal_mlp else ()):
                     b = self._mat_blocks[f"{p}.{key}"]
                     n_out = sum(it[1][0] for it in b.items)
                     setattr(L, "g_" + key + "_w", st.block_view(b, st.grad).view(n_out, b.numel // n_out))
+            if self.lora:
+                # frozen encoder vectors get no gradient (None pointers switch the kernels' parameter-gradient paths off); the
+                # adapters of this layer's wrapped linears, per mat-block key: (first row, n_out, A, B, dA, dB)
+                mats = {"g_qkv_w", "g_out_w", "g_fc1_w", "g_fc2_w", "g_tqkv_w", "g_tout_w", "g_tfc1_w", "g_tfc2_w"}
+                for nm in [k for k in vars(L) if k.startswith("g_") and k not in mats]:
+                    setattr(L, nm, None)
+                L.lora = {}
+                for key, row0, n_out, k_in, stem in self._lora_sites:
+                    if key.startswith(p + "."):
+                        a, bn = f"{stem}.lora_A.default.weight", f"{stem}.lora_B.default.weight"
+                        L.lora.setdefault(key[len(p) + 1:], []).append((row0, n_out, st.view(a), st.view(bn), st.gview(a), st.gview(bn)))
             self._lp.append(L)
 
     def _w(self, key):
@@ -364,21 +483,21 @@ class ClipTower(nn.Module):
 
     # ------------------------------------------------------------------ public forward (reference signature)
     def forward(self, pixel_values=None, output_attentions=None, output_hidden_states=None, return_dict=None, *,
-                input_ids=None, attention_mask=None, position_ids=None):
+                input_ids=None, attention_mask=None, position_ids=None, patch_keep=None):
         c = self.config
         if c.kind == "text" and input_ids is None and pixel_values is not None and pixel_values.dtype in (torch.int64, torch.int32):
             input_ids, pixel_values = pixel_values, None  # positional call of the text tower
         if c.kind == "vision":
             if pixel_values is None:
                 raise ValueError("You have to specify pixel_values")
-            inputs = (pixel_values,)
+            inputs = (pixel_values, patch_keep)
         else:
             if input_ids is None:
                 raise ValueError("You have to specify input_ids")
             inputs = (input_ids, attention_mask)
         self._ensure_ready()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
-        params = tuple(self.get_parameter(n) for n in self._param_names) if (need_grad and _GRAD_MODE == "autograd") else ()
+        params = tuple(self._param(n) for n in self._param_names if self.is_trainable(n)) if (need_grad and _GRAD_MODE == "autograd") else ()
         last, pooled = _TowerFn.apply(self._anchor, self, inputs, need_grad, *params)
         return (last, pooled)
 
@@ -396,8 +515,10 @@ class ClipTower(nn.Module):
         zero_grad(set_to_none=False) the buffers hold zeros, and adding to them is the same as storing.  In "autograd"
         gradient mode the values are handed to autograd, which does its own accumulation."""
         st = self._store
-        self._accumulate = bool(self._grad_fresh and _GRAD_MODE == "direct" and self._plist[0].grad is not None
-                                and st.grad is not None and self._plist[0].grad.data_ptr() == st.gview(self._param_names[0]).data_ptr())
+        first = next(n for n in self._param_names if self.is_trainable(n))
+        fp = self._param(first)
+        self._accumulate = bool(self._grad_fresh and _GRAD_MODE == "direct" and fp.grad is not None
+                                and st.grad is not None and fp.grad.data_ptr() == st.gview(first).data_ptr())
         if not self._accumulate:
             st.zero_accumulated()
 
@@ -409,7 +530,7 @@ class ClipTower(nn.Module):
         grad = st.ensure_grad()
         cache = self._grad_cache
         if cache is None or cache[0] is not grad:
-            cache = self._grad_cache = (grad, [(self.get_parameter(n), st.gview(n)) for n in self._param_names])
+            cache = self._grad_cache = (grad, [(self._param(n), st.gview(n)) for n in self._param_names if self.is_trainable(n)])
         for p, gv in cache[1]:
             if p.grad is not gv:
                 p.grad = gv
@@ -423,11 +544,20 @@ class ClipTower(nn.Module):
 # fill the chip like one long tower (their own 128x128 grids fill 59-88 % of it and run at ~480 TFLOP/s against ~1000 for the
 # video tower's).  With one lane this is exactly the single-tower path.
 # ======================================================================================================================
-def _linear_bwd_lanes(lanes, dys, xs, wts, g_ws, g_bs, rows, dx_outs=None, act=ops.ACT_NONE, aux_ins=None):
+def _linear_bwd_lanes(lanes, dys, xs, wts, g_ws, g_bs, rows, dx_outs=None, act=ops.ACT_NONE, aux_ins=None, lora_sites=None):
     """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result STORED
     into the fp32 gradient - or ADDED to it when this backward accumulates, ClipTower._begin_backward); db += colsum(dy) riding
-    in the same GEMM (tail of the gradient buffer); dx = dy W through the transposed compute-dtype shadow (NT form)."""
-    ops.gemm_grouped(dys, xs, g_ws, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_bs, accumulate=lanes[0]._accumulate)
+    in the same GEMM (tail of the gradient buffer); dx = dy W through the transposed compute-dtype shadow (NT form).
+    LoRA towers (`lora_sites` = per lane None: a frozen linear, or its adapters): a frozen linear has no weight gradient at all; a
+    wrapped one writes the full dW into its (scratch) gradient slot and derives dA / dB from it (csrc/lora.hip), which accumulate."""
+    if lora_sites is None:
+        ops.gemm_grouped(dys, xs, g_ws, trans_a=True, trans_b=True, splitk=0, K=rows, colsum_a=g_bs, accumulate=lanes[0]._accumulate)
+    elif lora_sites[0] is not None:
+        ops.gemm_grouped(dys, xs, g_ws, trans_a=True, trans_b=True, splitk=0, K=rows)
+        for t, g_w, sites in zip(lanes, g_ws, lora_sites):
+            scale = float(t.config.lora_alpha) / float(t.config.lora_r)
+            for row0, n_out, a, b, da, db in sites:
+                ops.lora_grad(g_w[row0:row0 + n_out], a, b, da, db, scale)
     if dx_outs is not None:
         ops.gemm_grouped(dys, wts, dx_outs, act=act, aux_in=aux_ins, M=rows)
     return dx_outs
@@ -494,13 +624,34 @@ def forward_lanes(towers, inputs, save: bool):
             ops.unfold_patches(pxs[g], U[g], c.patch_size)
         pe = E(N * P, d, device=dev, dtype=T)
         ops.gemm_grouped(U, [t._w("patch")[0] for t in towers], pe)
-        x0, h = E(N * S, d, **f32), E(N * S, d, **f32)
+        # PatchDropout (image/modeling_image.py:30-63,647): training mode and prob > 0 - the class token and K kept patch tokens
+        # of every frame go on; the gather rides in pre_layrnorm's row addressing (row r reads embedding row r + off[r]), the
+        # rest of the tower simply runs on S = 1 + K tokens per frame
+        S0, offs = S, [None for _ in G]
+        drop = [bool(c.force_patch_dropout > 0 and t.training) for t in towers]
+        if any(drop):
+            if not all(drop):
+                raise RuntimeError("towers run in lock-step must agree on train / eval mode (PatchDropout is active in training only)")
+            K = t0.patch_dropout.num_keep(P)
+            S = 1 + K
+            for g in G:
+                idx = inputs[g][1] if len(inputs[g]) > 1 and inputs[g][1] is not None else towers[g].patch_dropout.keep_indices(B, Tf, P)
+                idx = torch.as_tensor(idx).to("cpu", torch.int64)
+                want = (N if Tf == 1 else B, K)
+                if tuple(idx.shape) != want or int(idx.min()) < 0 or int(idx.max()) >= P:
+                    raise ValueError(f"patch_keep must hold {want} indices into the {P} patch tokens")
+                if Tf != 1:
+                    idx = idx.unsqueeze(1).repeat(1, Tf, 1).reshape(N, K)          # 'b t n -> (b t) n' (:55-56)
+                src = torch.cat([torch.zeros(N, 1, dtype=torch.int64), 1 + idx], dim=1) + torch.arange(N)[:, None] * S0
+                offs[g] = (src.reshape(-1) - torch.arange(N * S)).to(torch.int32).to(dev)
+        x0, h = E(N * S0, d, **f32), E(N * S, d, **f32)
         m0, r0 = E(N * S, **f32), E(N * S, **f32)
         for g in G:
             st = sts[g]
-            ops.embed_assemble(pe[g], st.view("embeddings.class_embedding"), st.view("embeddings.position_embedding.weight"), x0[g], N, S, d)
-            ops.layernorm_fwd(x0[g], st.view("pre_layrnorm.weight"), st.view("pre_layrnorm.bias"), h[g], m0[g], r0[g], N * S, d, c.layer_norm_eps)
-            ss[g].emb = (U[g], x0[g], m0[g], r0[g]) if save else None
+            ops.embed_assemble(pe[g], st.view("embeddings.class_embedding"), st.view("embeddings.position_embedding.weight"), x0[g], N, S0, d)
+            ops.layernorm_fwd(x0[g], st.view("pre_layrnorm.weight"), st.view("pre_layrnorm.bias"), h[g], m0[g], r0[g], N * S, d, c.layer_norm_eps,
+                              in_off=offs[g])
+            ss[g].emb = (U[g], x0[g], m0[g], r0[g], offs[g], S0) if save else None
         causal, key_mask = False, [None for _ in G]
     else:
         (ids, amask), = inputs          # (text towers are never grouped)
@@ -541,6 +692,22 @@ def forward_lanes(towers, inputs, save: bool):
                 for g in G:
                     recs[g].t = (h[g], xt[g], mt[g], rt[g], qkv[g], ctx[g], lse[g])
             h = h2
+            if c.temporal_mlp:
+                # h = h + temporal_mlp(temporal_layer_norm2(h)) (image/modeling_image.py:129-134): LayerNorm and MLP act row by row,
+                # so the '(b t) n d <-> (b n) t d' rearrangements around them change nothing
+                xm = E(rows, d, device=dev, dtype=T)
+                mm, rm = E(rows, **f32), E(rows, **f32)
+                for g in G:
+                    ops.layernorm_fwd(h[g], L[g].tln2_w, L[g].tln2_b, xm[g], mm[g], rm[g], rows, d, c.layer_norm_eps)
+                at = E(rows, f, device=dev, dtype=T)
+                ut = E(rows, f, device=dev, dtype=T) if save else None
+                ops.gemm_grouped(xm, W(f"{pfx}.tfc1", 0), at, bias=[l.tfc1_b for l in L], act=act, aux_out=ut)
+                h3 = E(rows, d, **f32)
+                ops.gemm_grouped(at, W(f"{pfx}.tfc2", 0), h3, bias=[l.tfc2_b for l in L], resid=h)
+                if save:
+                    for g in G:
+                        recs[g].tm = (h[g], xm[g], mm[g], rm[g], ut[g], at[g])
+                h = h3
         x1 = E(rows, d, device=dev, dtype=T)
         m1, r1 = E(rows, **f32), E(rows, **f32)
         for g in G:
@@ -647,21 +814,23 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
     W = lambda key, which: [t._w(key)[which] for t in towers]            # noqa: E731
     for i in reversed(range(c.num_hidden_layers)):
         L = [t._lp[i] for t in towers]
+        # LoRA towers: per linear None (frozen: no dW) or its adapters (dW into scratch, then dA / dB); plain towers: None = the usual dW
+        LS = (lambda key: [l.lora.get(key) for l in L]) if t0.lora else (lambda key: None)       # noqa: E731
         pfx = f"encoder.layers.{i}"
         recs = [states[g].layers[i] for g in G]
         # ---- MLP block: h3 = h2 + fc2(act(fc1(LN2(h2))))
         h2, x2, m2, r2, u, a = (list(v) for v in zip(*[r.m for r in recs]))
         du = E(rows, f, device=dev, dtype=T)
-        _linear_bwd_lanes(towers, dh_T, a, W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], rows, dx_outs=du, act=dact, aux_ins=u)
+        _linear_bwd_lanes(towers, dh_T, a, W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], rows, dx_outs=du, act=dact, aux_ins=u, lora_sites=LS("fc2"))
         dx2 = E(rows, d, device=dev, dtype=T)
-        _linear_bwd_lanes(towers, du, x2, W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], rows, dx_outs=dx2)
+        _linear_bwd_lanes(towers, du, x2, W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], rows, dx_outs=dx2, lora_sites=LS("fc1"))
         for g in G:
             ops.layernorm_bwd(dx2[g], h2[g], m2[g], r2[g], L[g].ln2_w, dh[g], L[g].g_ln2_w, L[g].g_ln2_b, rows, d, accumulate=True, dx_cast=dh_T[g])
         # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
         hin, x1, m1, r1, qkv, ctx, lse = (list(v) for v in zip(*[r.a for r in recs]))
         dctx_all = torch.empty(rows * len(towers), d, device=dev, dtype=T)
         dctx = [dctx_all[g * rows:(g + 1) * rows] for g in G]
-        _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], rows, dx_outs=dctx)
+        _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], rows, dx_outs=dctx, lora_sites=LS("out"))
         if len(towers) > 1:      # one launch over every lane's sequences (forward_lanes made the saved buffers slices of one allocation)
             qkv_all, ctx_all, lse_all = recs[0].a_all
             dqkv_all = torch.empty(rows * len(towers), 3 * d, device=dev, dtype=T)
@@ -671,21 +840,29 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
             dqkv = E(rows, 3 * d, device=dev, dtype=T)
             ops.attention_bwd(qkv[0], ctx[0], dctx[0], lse[0], dqkv[0], N, S, H, hd, causal=states[0].causal, key_mask=states[0].key_mask)
         dx1 = E(rows, d, device=dev, dtype=T)
-        _linear_bwd_lanes(towers, dqkv, x1, W(f"{pfx}.qkv", 1), [l.g_qkv_w for l in L], [l.g_qkv_b for l in L], rows, dx_outs=dx1)
+        _linear_bwd_lanes(towers, dqkv, x1, W(f"{pfx}.qkv", 1), [l.g_qkv_w for l in L], [l.g_qkv_b for l in L], rows, dx_outs=dx1, lora_sites=LS("qkv"))
         for g in G:
             ops.layernorm_bwd(dx1[g], hin[g], m1[g], r1[g], L[g].ln1_w, dh[g], L[g].g_ln1_w, L[g].g_ln1_b, rows, d, accumulate=True, dx_cast=dh_T[g])
+        if c.temporal_mlp:
+            hin, xm, mm, rm, ut, at = (list(v) for v in zip(*[r.tm for r in recs]))
+            dut = E(rows, f, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, dh_T, at, W(f"{pfx}.tfc2", 1), [l.g_tfc2_w for l in L], [l.g_tfc2_b for l in L], rows, dx_outs=dut, act=dact, aux_ins=ut, lora_sites=LS("tfc2"))
+            dxm = E(rows, d, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, dut, xm, W(f"{pfx}.tfc1", 1), [l.g_tfc1_w for l in L], [l.g_tfc1_b for l in L], rows, dx_outs=dxm, lora_sites=LS("tfc1"))
+            for g in G:
+                ops.layernorm_bwd(dxm[g], hin[g], mm[g], rm[g], L[g].tln2_w, dh[g], L[g].g_tln2_w, L[g].g_tln2_b, rows, d, accumulate=True, dx_cast=dh_T[g])
         if c.add_time_attn:
             hin, xt, mt, rt, qkv, ctx, lse = (list(v) for v in zip(*[r.t for r in recs]))
             dctx = E(rows, d, device=dev, dtype=T)
-            _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.tout", 1), [l.g_tout_w for l in L], [l.g_tout_b for l in L], rows, dx_outs=dctx)
+            _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.tout", 1), [l.g_tout_w for l in L], [l.g_tout_b for l in L], rows, dx_outs=dctx, lora_sites=LS("tout"))
             dqkv = E(rows, 3 * d, device=dev, dtype=T)
             for g in G:
                 ops.attention_bwd(qkv[g], ctx[g], dctx[g], lse[g], dqkv[g], B * S, Tf, H, hd, seq_div=S, seq_outer=Tf * S, seq_inner=1, tok_stride=S)
             dxt = E(rows, d, device=dev, dtype=T)
-            _linear_bwd_lanes(towers, dqkv, xt, W(f"{pfx}.tqkv", 1), [l.g_tqkv_w for l in L], [l.g_tqkv_b for l in L], rows, dx_outs=dxt)
+            _linear_bwd_lanes(towers, dqkv, xt, W(f"{pfx}.tqkv", 1), [l.g_tqkv_w for l in L], [l.g_tqkv_b for l in L], rows, dx_outs=dxt, lora_sites=LS("tqkv"))
             for g in G:
                 ops.layernorm_bwd(dxt[g], hin[g], mt[g], rt[g], L[g].tln_w, dh[g], L[g].g_tln_w, L[g].g_tln_b, rows, d, accumulate=True, dx_cast=dh_T[g])
-                if Tf != 1:
+                if Tf != 1 and L[g].g_temb is not None:
                     ops.colsum(dh[g], L[g].g_temb, div=S, mod=Tf, R=rows)
         for g in G:
             states[g].layers[i] = None
@@ -697,19 +874,21 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
                     t._bucket_hook(t, *t.layer_mat_range(i, min(i + t.bucket_layers, c.num_hidden_layers) - 1))
     # ---- embeddings
     if c.kind == "vision":
-        P = S - 1
+        S0 = states[0].emb[5]               # tokens per frame BEFORE PatchDropout (== S when it was the identity)
+        P = S0 - 1
         dpe = E(N * P, d, device=dev, dtype=T)
         Us = []
         for g in G:
             st, s = sts[g], states[g]
             gv = st.gview
-            U, x0, m0, r0 = s.emb
-            dx = torch.empty(rows, d, **f32)
+            U, x0, m0, r0, off, _ = s.emb
+            # (PatchDropout: the gradient is scattered back to the kept tokens' embedding rows, the dropped ones get zero)
+            dx = torch.empty(rows, d, **f32) if off is None else torch.zeros(N * S0, d, **f32)
             ops.layernorm_bwd(dh[g], x0, m0, r0, st.view("pre_layrnorm.weight"), dx, gv("pre_layrnorm.weight"), gv("pre_layrnorm.bias"),
-                              rows, d, accumulate=False)
-            # position-embedding gradient: sum over frames of dx[n, s, :] = a plain column sum of dx viewed as [N, S*d]
-            ops.colsum(dx.view(N, S * d), gv("embeddings.position_embedding.weight").view(S * d), R=N)
-            ops.colsum(dx.view(N, S * d)[:, :d], gv("embeddings.class_embedding"), R=N)
+                              rows, d, accumulate=False, in_off=off)
+            # position-embedding gradient: sum over frames of dx[n, s, :] = a plain column sum of dx viewed as [N, S0*d]
+            ops.colsum(dx.view(N, S0 * d), gv("embeddings.position_embedding.weight").view(S0 * d), R=N)
+            ops.colsum(dx.view(N, S0 * d)[:, :d], gv("embeddings.class_embedding"), R=N)
             ops.cast_rows(dx, dpe[g], N * P, d, rdiv=P, roff=1)
             Us.append(U)
         gwp = []
@@ -752,7 +931,7 @@ class _TowerFn(torch.autograd.Function):
             tower._post_backward(tower)
         if ctx.nparams:
             st = tower._store
-            grads = tuple(st.gview(n).clone() for n in tower._param_names)
+            grads = tuple(st.gview(n).clone() for n in tower._param_names if tower.is_trainable(n))
             return (_anchor_grad(d_last, d_pooled), None, None, None) + grads
         tower.attach_grads()
         return (_anchor_grad(d_last, d_pooled), None, None, None)
@@ -788,7 +967,7 @@ class _TowerGroupFn(torch.autograd.Function):
 def run_towers(towers, kwargs_list):
     """[(last_hidden_state, pooled_output)] of `towers[i](**kwargs_list[i])`; shape-identical vision towers run in lock-step with
     grouped GEMM launches (one tile grid for all of them), anything else one after the other - same results either way."""
-    inputs = [(kw.get("pixel_values"),) for kw in kwargs_list]
+    inputs = [(kw.get("pixel_values"), kw.get("patch_keep")) for kw in kwargs_list]
     grouped = (len(towers) > 1 and _GRAD_MODE == "direct" and all(i[0] is not None for i in inputs) and lanes_compatible(towers, inputs)
                and len({id(t) for t in towers}) == len(towers))
     if not grouped:

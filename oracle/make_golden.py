@@ -52,7 +52,8 @@ def vision_fixture(name, modality, cfg: O.VisionCfg, batch, seed_w, seed_x, stor
     vc = cfgm.CLIPVisionConfig(hidden_size=cfg.hidden_size, intermediate_size=cfg.intermediate_size,
                                num_hidden_layers=cfg.num_hidden_layers, num_attention_heads=cfg.num_attention_heads,
                                image_size=cfg.image_size, patch_size=cfg.patch_size, lora_r=0,
-                               add_time_attn=cfg.add_time_attn, num_frames=cfg.num_frames)
+                               add_time_attn=cfg.add_time_attn, num_frames=cfg.num_frames,
+                               force_patch_dropout=getattr(cfg, "force_patch_dropout", 0.0))
     tower = mod.CLIPVisionTransformer(vc).eval()
     params = O.init_tower_params(cfg, seed_w)
     res = tower.load_state_dict(params, strict=False)
@@ -61,9 +62,23 @@ def vision_fixture(name, modality, cfg: O.VisionCfg, batch, seed_w, seed_x, stor
         x = torch.randn(batch, cfg.num_channels, cfg.num_frames, cfg.image_size, cfg.image_size, generator=_gen(seed_x))
     else:
         x = torch.randn(batch, cfg.num_channels, cfg.image_size, cfg.image_size, generator=_gen(seed_x))
-    last, pooled = tower(x, return_dict=False)[:2]
+    keep = None
+    if getattr(cfg, "force_patch_dropout", 0.0) > 0:
+        # PatchDropout acts in training mode: the reference draws torch.randn(batch, num_tokens).topk(k) from the global CPU generator
+        # inside forward (its first RNG use: attention dropout is 0).  Seed, run, then re-seed and repeat the draw to learn the indices.
+        tower.train()
+        torch.manual_seed(seed_x + 500)
+        last, pooled = tower(x, return_dict=False)[:2]
+        torch.manual_seed(seed_x + 500)
+        ntok = cfg.num_patches
+        kk = max(1, int(ntok * (1 - cfg.force_patch_dropout)))
+        keep = torch.randn(batch if cfg.num_frames > 1 else x.shape[0], ntok).topk(kk, dim=-1).indices
+    else:
+        last, pooled = tower(x, return_dict=False)[:2]
     fix = {"cfg": cfg.__dict__.copy(), "seed_w": seed_w, "pixel_values": x, "last_hidden_state": last.detach(),
            "pooled": pooled.detach()}
+    if keep is not None:
+        fix["patch_keep"] = keep
     if grad_names:
         cot_p = torch.randn(pooled.shape, generator=_gen(seed_x + 100))
         cot_h = torch.randn(last.shape, generator=_gen(seed_x + 101)) * 0.1
@@ -81,7 +96,7 @@ def vision_fixture(name, modality, cfg: O.VisionCfg, batch, seed_w, seed_x, stor
     torch.save(fix, os.path.join(OUT, name + ".pt"))
     # cross-check the oracle right away
     with torch.no_grad():
-        h, p = O.vision_tower(x, params, cfg)
+        h, p = O.vision_tower(x, params, cfg, patch_keep=keep)
     print(f"{name}: ref-vs-oracle last {float((h - last).abs().max()):.2e} pooled {float((p - pooled).abs().max()):.2e}")
 
 
@@ -362,6 +377,18 @@ def main():
                              f"{lname}.temporal_attn.out_proj.bias", f"{lname}.temporal_layer_norm1.weight")
     run(vision_fixture, "video_tiny", "video", O.VisionCfg(**tiny, add_time_attn=True, num_frames=4), batch=2, seed_w=3, seed_x=4,
                    grad_names=vid_grads)
+    # the IMAGE-family time branch (image/modeling_image.py:83-84,129-134): the same layer with a temporal MLP behind the temporal
+    # attention, which the video file removed - run on the reference's image tower with add_time_attn=True
+    run(vision_fixture, "image_time_tiny", "image", O.VisionCfg(**tiny, add_time_attn=True, num_frames=4, temporal_mlp=True), batch=2,
+        seed_w=13, seed_x=14, grad_names=vid_grads + (f"{lname}.temporal_mlp.fc1.weight", f"{lname}.temporal_mlp.fc2.bias",
+                                                     f"{lname}.temporal_layer_norm2.weight", "encoder.layers.1.temporal_mlp.fc2.weight"))
+    # PatchDropout in training mode (image/modeling_image.py:30-63): 64 x 64 images = 16 patch tokens, half of them dropped; once per
+    # frame (T = 1) and once with the draw shared by a sample's four frames (T > 1)
+    pd = dict(hidden_size=64, intermediate_size=128, num_hidden_layers=2, num_attention_heads=2, image_size=64, patch_size=16)
+    run(vision_fixture, "patch_dropout_tiny", "image", O.VisionCfg(**pd, force_patch_dropout=0.5), batch=3, seed_w=15, seed_x=16,
+        grad_names=vis_grads)
+    run(vision_fixture, "patch_dropout_video_tiny", "video", O.VisionCfg(**pd, add_time_attn=True, num_frames=4, force_patch_dropout=0.4),
+        batch=2, seed_w=17, seed_x=18, grad_names=vid_grads)
     # a 197-token, head_dim-64 case small enough to commit: exercises the production attention shape
     run(vision_fixture, "vision_s197", "image",
                    O.VisionCfg(hidden_size=128, intermediate_size=256, num_hidden_layers=1, num_attention_heads=2,

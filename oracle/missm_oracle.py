@@ -57,6 +57,11 @@ class VisionCfg:
     # image/audio/depth/thermal modeling files keep a temporal MLP in the time branch
     # (image/modeling_image.py:83-84,129-134); the video file removed it (video/modeling_video.py:189-190,235-240)
     temporal_mlp: bool = False
+    force_patch_dropout: float = 0.0  # configuration_image.py:199; PatchDropout is active in training mode only
+    # LoRA over the vision encoder (configuration_image.py:200-202; image/modeling_image.py:775-793); 0 = plain weights
+    lora_r: int = 0
+    lora_alpha: float = 16.0
+    lora_dropout: float = 0.0
 
     @property
     def num_patches(self) -> int:
@@ -102,6 +107,31 @@ def activation(x: Tensor, name: str) -> Tensor:
     raise ValueError(f"unsupported hidden_act {name!r}")
 
 
+def linear(x: Tensor, p: Params, name: str, lora_scaling: float = 0.0) -> Tensor:
+    """``nn.Linear`` - or, where ``convert_to_lora`` (image/modeling_image.py:775-793) wrapped it, peft's ``lora.Linear`` forward
+    restated from its published definition (peft is absent from this image and unpinned upstream: PARITY UNPINNED for the wrapper):
+        result = base_layer(x) + lora_B(lora_A(lora_dropout(x))) * scaling,   scaling = lora_alpha / r
+    with lora_dropout = 0.0 (the reference default).  Keys are the tower's state-dict keys with peft's wrapper prefixes removed
+    (``normalize_peft_keys``): ``<name>.weight`` / ``.bias`` for the base layer, ``<name>.lora_A.default.weight`` [r, in] and
+    ``<name>.lora_B.default.weight`` [out, r] for the adapter; a linear without adapter keys is a plain linear."""
+    y = F.linear(x, p[name + ".weight"], p.get(name + ".bias"))
+    a = p.get(name + ".lora_A.default.weight")
+    if a is not None and lora_scaling:
+        y = y + F.linear(F.linear(x, a), p[name + ".lora_B.default.weight"]) * lora_scaling
+    return y
+
+
+def normalize_peft_keys(sd: Params) -> Params:
+    """peft state-dict keys (``encoder.base_model.model.layers.N.self_attn.q_proj.base_layer.weight``) -> the oracle's
+    (``encoder.layers.N.self_attn.q_proj.weight``); adapter keys keep their ``lora_A.default.weight`` leaf"""
+    return {k.replace(".base_model.model.", ".").replace(".base_layer.", "."): v for k, v in sd.items()}
+
+
+def lora_scaling(cfg) -> float:
+    r = getattr(cfg, "lora_r", 0)
+    return float(getattr(cfg, "lora_alpha", 0.0)) / r if r else 0.0
+
+
 def layer_norm(x: Tensor, p: Params, prefix: str, eps: float) -> Tensor:
     """``nn.LayerNorm(embed_dim, eps)`` sites: image/modeling_image.py:70,72,82,84,465,604,606."""
     return F.layer_norm(x, (x.shape[-1],), p[prefix + ".weight"], p[prefix + ".bias"], eps)
@@ -109,7 +139,7 @@ def layer_norm(x: Tensor, p: Params, prefix: str, eps: float) -> Tensor:
 
 def clip_attention(x: Tensor, p: Params, prefix: str, num_heads: int,
                    attention_mask: Optional[Tensor] = None,
-                   causal_attention_mask: Optional[Tensor] = None) -> Tensor:
+                   causal_attention_mask: Optional[Tensor] = None, lora: float = 0.0) -> Tensor:
     """``CLIPAttention.forward`` (third-party; called at image/modeling_image.py:121-126,140-145).
 
     q = (x Wq^T + bq) * hd^-1/2 ; scores = q k^T (+ causal) (+ padding) ; softmax over keys ;
@@ -118,9 +148,9 @@ def clip_attention(x: Tensor, p: Params, prefix: str, num_heads: int,
     bsz, tgt, dim = x.shape
     hd = dim // num_heads
     scale = hd ** -0.5
-    q = F.linear(x, p[prefix + ".q_proj.weight"], p[prefix + ".q_proj.bias"]) * scale
-    k = F.linear(x, p[prefix + ".k_proj.weight"], p[prefix + ".k_proj.bias"])
-    v = F.linear(x, p[prefix + ".v_proj.weight"], p[prefix + ".v_proj.bias"])
+    q = linear(x, p, prefix + ".q_proj", lora) * scale
+    k = linear(x, p, prefix + ".k_proj", lora)
+    v = linear(x, p, prefix + ".v_proj", lora)
 
     def heads(t: Tensor) -> Tensor:
         return t.view(bsz, tgt, num_heads, hd).transpose(1, 2)  # [B,H,S,hd]
@@ -134,14 +164,14 @@ def clip_attention(x: Tensor, p: Params, prefix: str, num_heads: int,
     w = torch.softmax(w, dim=-1)
     o = torch.matmul(w, v)  # [B,H,S,hd]
     o = o.transpose(1, 2).reshape(bsz, tgt, dim)
-    return F.linear(o, p[prefix + ".out_proj.weight"], p[prefix + ".out_proj.bias"])
+    return linear(o, p, prefix + ".out_proj", lora)
 
 
-def clip_mlp(x: Tensor, p: Params, prefix: str, act: str) -> Tensor:
+def clip_mlp(x: Tensor, p: Params, prefix: str, act: str, lora: float = 0.0) -> Tensor:
     """``CLIPMLP.forward`` (third-party; called at image/modeling_image.py:150): fc2(act(fc1(x)))."""
-    h = F.linear(x, p[prefix + ".fc1.weight"], p[prefix + ".fc1.bias"])
+    h = linear(x, p, prefix + ".fc1", lora)
     h = activation(h, act)
-    return F.linear(h, p[prefix + ".fc2.weight"], p[prefix + ".fc2.bias"])
+    return linear(h, p, prefix + ".fc2", lora)
 
 
 def make_causal_mask(seq: int, dtype: torch.dtype) -> Tensor:
@@ -166,6 +196,7 @@ def encoder_layer(h: Tensor, p: Params, prefix: str, cfg, attention_mask=None, c
     """``CLIPEncoderLayer.forward``.  ``h`` is [(b t), n, d] for vision, [b, s, d] for text."""
     nh = cfg.num_attention_heads
     eps = cfg.layer_norm_eps
+    ls = lora_scaling(cfg)      # adapters exist only on the linears convert_to_lora targets (:778-783); `linear` looks for their keys
     if cfg.add_time_attn:
         bt, n, d = h.shape
         t = cfg.num_frames
@@ -178,23 +209,23 @@ def encoder_layer(h: Tensor, p: Params, prefix: str, cfg, attention_mask=None, c
         residual = h
         hh = h.view(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
         hh = layer_norm(hh, p, prefix + ".temporal_layer_norm1", eps)
-        hh = clip_attention(hh, p, prefix + ".temporal_attn", nh, attention_mask, causal_attention_mask)
+        hh = clip_attention(hh, p, prefix + ".temporal_attn", nh, attention_mask, causal_attention_mask, lora=ls)
         h = residual + hh.view(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)
         if cfg.temporal_mlp:  # image-family only (:129-134)
             residual = h
             hh = h.view(b, t, n, d).permute(0, 2, 1, 3).reshape(b * n, t, d)
             hh = layer_norm(hh, p, prefix + ".temporal_layer_norm2", eps)
-            hh = clip_mlp(hh, p, prefix + ".temporal_mlp", cfg.hidden_act)
+            hh = clip_mlp(hh, p, prefix + ".temporal_mlp", cfg.hidden_act, lora=ls)
             h = residual + hh.view(b, n, t, d).permute(0, 2, 1, 3).reshape(bt, n, d)
     # spatial attn (:137-146)
     residual = h
     x = layer_norm(h, p, prefix + ".layer_norm1", eps)
-    x = clip_attention(x, p, prefix + ".self_attn", nh, attention_mask, causal_attention_mask)
+    x = clip_attention(x, p, prefix + ".self_attn", nh, attention_mask, causal_attention_mask, lora=ls)
     h = residual + x
     # mlp (:148-151)
     residual = h
     x = layer_norm(h, p, prefix + ".layer_norm2", eps)
-    x = clip_mlp(x, p, prefix + ".mlp", cfg.hidden_act)
+    x = clip_mlp(x, p, prefix + ".mlp", cfg.hidden_act, lora=ls)
     return residual + x
 
 
@@ -219,9 +250,21 @@ def vision_embeddings(pixel_values: Tensor, p: Params, cfg: VisionCfg) -> Tensor
     return x + p["embeddings.position_embedding.weight"][None, : x.shape[1]]
 
 
-def vision_tower(pixel_values: Tensor, p: Params, cfg: VisionCfg) -> Tuple[Tensor, Tensor]:
+def patch_dropout(x: Tensor, keep: Tensor, B: int, T: int) -> Tensor:
+    """``PatchDropout.forward`` image/modeling_image.py:30-63 in training mode with prob > 0, the random draw handed in:
+    ``keep`` = ``torch.randn(batch, num_tokens).topk(num_patches_keep).indices`` ([(B T), K] for T == 1, else [B, K] shared by a
+    sample's frames); the class token is excluded from the draw and kept."""
+    cls_tokens, x = x[:, :1], x[:, 1:]
+    if T != 1:
+        keep = keep.unsqueeze(1).repeat(1, T, 1).reshape(B * T, -1)         # 'b t n -> (b t) n'
+    x = x[torch.arange(x.shape[0])[:, None], keep]
+    return torch.cat((cls_tokens, x), dim=1)
+
+
+def vision_tower(pixel_values: Tensor, p: Params, cfg: VisionCfg, patch_keep: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
     """``CLIPVisionTransformer.forward`` image/modeling_image.py:610-672 / video/modeling_video.py:723-784.
-    Returns (last_hidden_state [(B T), S, d], pooled [B, d])."""
+    Returns (last_hidden_state [(B T), S, d], pooled [B, d]).  ``patch_keep``: the kept-token indices of a training-mode
+    PatchDropout (None: eval mode / prob 0 = identity)."""
     if pixel_values is None:
         raise ValueError("You have to specify pixel_values")
     if pixel_values.dim() == 7:  # :630-634
@@ -234,7 +277,9 @@ def vision_tower(pixel_values: Tensor, p: Params, cfg: VisionCfg) -> Tuple[Tenso
     else:
         B, T = pixel_values.shape[0], 1
     h = vision_embeddings(pixel_values, p, cfg)
-    # PatchDropout (:30-63) is the identity at force_patch_dropout == 0 (default) and in eval.
+    # PatchDropout (:30-63,647) is the identity at force_patch_dropout == 0 (default) and in eval.
+    if patch_keep is not None:
+        h = patch_dropout(h, patch_keep, B, T)
     h = layer_norm(h, p, "pre_layrnorm", cfg.layer_norm_eps)
     h = encoder(h, p, cfg)
     pooled = layer_norm(h[:, 0, :], p, "post_layernorm", cfg.layer_norm_eps)

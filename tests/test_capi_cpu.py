@@ -106,15 +106,43 @@ def test_lora_checkpoint_merge_matches_unmerged_adapter(tmp_path):
     d.mkdir(parents=True)
     json.dump({"vision_config": dict(asdict(vc), lora_r=r, lora_alpha=alpha), "text_config": asdict(tc), "projection_dim": 16}, open(d / "config.json", "w"))
     torch.save(wrapped, d / "pytorch_model.bin")
-    loaded = LanguageBindImage.from_pretrained("LanguageBind/LanguageBind_Image", cache_dir=str(tmp_path), seed=9)
+    loaded = LanguageBindImage.from_pretrained("LanguageBind/LanguageBind_Image", cache_dir=str(tmp_path), seed=9, merge_lora=True)
     for k, v in loaded.state_dict().items():
         assert torch.allclose(v, merged[k], atol=1e-6), k
+    # default: as the reference builds it - the peft-wrapped keys load one to one into a LoRA tower (frozen encoder, trainable adapters)
+    lora = LanguageBindImage.from_pretrained("LanguageBind/LanguageBind_Image", cache_dir=str(tmp_path), seed=9)
+    assert lora.vision_model.lora and lora.vision_model.config.lora_r == r
+    sd = lora.state_dict()
+    assert set(sd) == set(wrapped)
+    for k, v in wrapped.items():
+        assert torch.equal(sd[k], v), k
+    train = {k for k, p in lora.vision_model.named_parameters() if p.requires_grad}
+    assert all((".lora_" in k) or not k.startswith("encoder.") for k in train) and any(".lora_A." in k for k in train)
+    assert {"embeddings.class_embedding", "pre_layrnorm.weight", "post_layernorm.bias"} <= train
+    assert not any(p.requires_grad for k, p in lora.vision_model.named_parameters() if k.startswith("encoder.") and ".lora_" not in k)
 
 
-def test_unsupported_config_options_fail_loudly():
+def test_config_options_are_validated_and_patch_dropout_draws_like_the_reference():
     import pytest
-    from missm_benchmark_amd.towers import ClipTower, TowerConfig
+    import torch
+    from missm_benchmark_amd.towers import ClipTower, PatchDropout, TowerConfig
     tiny = dict(hidden_size=32, intermediate_size=64, num_hidden_layers=1, num_attention_heads=2, image_size=32, patch_size=16)
-    with pytest.raises(NotImplementedError, match="force_patch_dropout"):
-        ClipTower(TowerConfig(kind="vision", force_patch_dropout=0.5, **tiny))
-    ClipTower(TowerConfig(kind="vision", force_patch_dropout=0.0, **tiny))
+    with pytest.raises(ValueError, match="force_patch_dropout"):
+        ClipTower(TowerConfig(kind="vision", force_patch_dropout=1.0, **tiny))
+    with pytest.raises(ValueError, match="temporal_mlp"):
+        ClipTower(TowerConfig(kind="vision", temporal_mlp=True, **tiny))             # the time branch's MLP needs add_time_attn
+    t = ClipTower(TowerConfig(kind="vision", force_patch_dropout=0.5, **tiny))
+    assert t.patch_dropout.prob == 0.5 and t.patch_dropout.num_keep(196) == 98 and PatchDropout(0.99).num_keep(4) == 1
+    # the draw is the reference's (image/modeling_image.py:47-56): randn(batch, tokens).topk(k) on the CPU generator
+    torch.manual_seed(5)
+    a = t.patch_dropout.keep_indices(3, 1, 16)
+    torch.manual_seed(5)
+    assert torch.equal(a, torch.randn(3, 16).topk(8, dim=-1).indices)
+    torch.manual_seed(6)
+    b = t.patch_dropout.keep_indices(2, 4, 16)                                         # T > 1: one draw per SAMPLE
+    torch.manual_seed(6)
+    assert torch.equal(b, torch.randn(2, 16).topk(8, dim=-1).indices)
+    tm = ClipTower(TowerConfig(kind="vision", add_time_attn=True, num_frames=2, temporal_mlp=True, **tiny))
+    keys = set(tm.state_dict())
+    assert {"encoder.layers.0.temporal_mlp.fc1.weight", "encoder.layers.0.temporal_mlp.fc2.bias",
+            "encoder.layers.0.temporal_layer_norm2.weight"} <= keys

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _model(seed=0):
+def _model(seed=0, language=False):
     torch.manual_seed(1000 + seed)   # the fusion head draws from torch's global RNG (like the reference's nn.Linear init)
     sys.path.insert(0, ROOT)
     import missm_benchmark_amd as M
@@ -28,14 +28,20 @@ def _model(seed=0):
                        max_position_embeddings=8)
     enc = lb.LanguageBind({"image": "i", "video": "v"}, configs=cfgs, text_config=tcfg, projection_dim=32, compute_dtype=torch.float32,
                           seed=seed)
-    args = types.SimpleNamespace(modality_types=["image", "video"], feature_dims=32, fusion_dim=16, dropout_prob=0.0, fusion_type="sum")
+    mods = (["language"] if language else []) + ["image", "video"]
+    args = types.SimpleNamespace(modality_types=mods, feature_dims=32, fusion_dim=16, dropout_prob=0.0, fusion_type="sum")
     return base.finetune_model(args, 3, enc)
 
 
-def _batch(rank, B=4):
+def _batch(rank, B=4, language=False):
     g = torch.Generator().manual_seed(50 + rank)
     data = {"image": {"pixel_values": torch.randn(B, 3, 32, 32, generator=g)},
             "video": {"pixel_values": torch.randn(B, 3, 4, 32, 32, generator=g)}}
+    if language:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import missm_oracle as O
+        ids, mask = O.synth_text_batch(B, 8, 90 + rank, vocab=64)
+        data = {"language": {"input_ids": ids, "attention_mask": mask}, **data}
     missing = torch.tensor([0, 4, 2, 0])[:B]
     labels = torch.randint(0, 3, (B,), generator=g)
     return data, missing, labels
@@ -152,3 +158,76 @@ def test_two_ranks_match_single_process_on_concatenated_batch():
         ref = ograd(k)
         err = float((res[0][1][0][k] - ref).abs().max() / ref.abs().max())
         assert err < 2e-3, (k, err)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------
+# The reference's own wrap (train_ddp.py:188-189): SyncBatchNorm.convert_sync_batchnorm + DistributedDataParallel(device_ids=
+# [local_rank], broadcast_buffers=True, find_unused_parameters=False) around the drop-in model, gradients handed to autograd
+# (towers.set_grad_mode("autograd")) - against the bundled engine on the same two ranks (VERDICT r2 #6 / missing #3).
+# ---------------------------------------------------------------------------------------------------------------------------
+DDP_KEYS = KEYS + ["encoder.modality_encoder.language.embeddings.token_embedding.weight",
+                   "encoder.modality_encoder.language.encoder.layers.0.self_attn.v_proj.weight",
+                   "encoder.modality_encoder.image.pre_layrnorm.bias", "fusion.modal_proj.language.bias"]
+
+
+def _ddp_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    try:
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        from torch.nn.parallel import DistributedDataParallel as DDP
+        model = _model(seed=7 * (rank + 1), language=True).cuda()     # different init per rank: DDP's constructor broadcasts rank 0's
+        from missm_benchmark_amd import towers
+        from missm_benchmark_amd.engine import TrainEngine
+        from missm_benchmark_amd.nn import HipCrossEntropyLoss
+        crit = HipCrossEntropyLoss()
+        data, missing, labels = _batch(rank, language=True)
+        gdata = {m: {k: v.cuda() for k, v in d.items()} for m, d in data.items()}
+        towers.set_grad_mode("autograd")
+        ddp = DDP(torch.nn.SyncBatchNorm.convert_sync_batchnorm(model), device_ids=[0], broadcast_buffers=True, find_unused_parameters=False)
+        for _ in range(2):       # a second iteration: where a registered parameter without a gradient would make the reducer raise
+            ddp.zero_grad(set_to_none=True)
+            crit(ddp(gdata, missing.cuda()), labels.cuda()).backward()
+        torch.cuda.synchronize()
+        g_ddp = {k: ddp.module.get_parameter(k).grad.detach().cpu().numpy() for k in DDP_KEYS}
+        n_grad = sum(p.grad is not None for p in ddp.module.parameters()), sum(1 for _ in ddp.module.parameters())
+        towers.set_grad_mode("direct")
+        model2 = _model(seed=7 * (rank + 1), language=True).cuda()
+        eng = TrainEngine(model2, lr=1e-3, overlap=True)              # broadcasts rank 0's parameters, like the DDP constructor
+        eng.zero_grad()
+        crit(model2(gdata, missing.cuda()), labels.cuda()).backward()
+        eng.reduce_gradients()
+        torch.cuda.synchronize()
+        g_eng = {k: (model2.get_parameter(k).grad.detach() / eng.world).cpu().numpy() for k in DDP_KEYS}
+        same_init = all(bool(torch.equal(a.detach().cpu(), b.detach().cpu())) for a, b in zip(ddp.module.parameters(), model2.parameters()))
+        q.put((rank, (g_ddp, g_eng, n_grad, same_init), ""))
+        dist.destroy_process_group()
+    except Exception:  # pragma: no cover
+        import traceback
+        q.put((rank, None, traceback.format_exc()))
+
+
+def test_distributed_data_parallel_wrap_equals_engine():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29950 + (os.getpid() % 300)
+    procs = [ctx.Process(target=_ddp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[2] == "", r[2]
+    for rank, (g_ddp, g_eng, (with_grad, total), same_init), _ in res:
+        assert with_grad == total, f"rank {rank}: {total - with_grad} registered parameters got no gradient through DDP"
+        assert same_init, "DDP's and the engine's broadcast left different parameters"
+        for k in DDP_KEYS:
+            a, b = torch.from_numpy(g_ddp[k]), torch.from_numpy(g_eng[k])
+            err = float((a - b).abs().max() / b.abs().max())
+            assert err < 1e-4, (rank, k, err)                          # DDP's averaged gradient = the engine's reduced mean gradient
+    for k in DDP_KEYS:                                                 # and both ranks hold the same reduced values
+        assert (res[0][1][0][k] == res[1][1][0][k]).all(), k

@@ -24,7 +24,7 @@ def _check_vision(name):
     params = fix.get("params") or O.init_tower_params(cfg, fix["seed_w"])
     params = {k: v.clone().requires_grad_(True) for k, v in params.items()}
     x = _vision_inputs(fix, cfg)
-    last, pooled = O.vision_tower(x, params, cfg)
+    last, pooled = O.vision_tower(x, params, cfg, patch_keep=fix.get("patch_keep"))
     assert (pooled - fix["pooled"]).abs().max() < TOL
     if "last_hidden_state" in fix:
         assert (last - fix["last_hidden_state"]).abs().max() < TOL
@@ -51,6 +51,20 @@ def test_vision_tiny():
 
 def test_video_tiny_time_attention():
     _check_vision("video_tiny")
+
+
+def test_image_family_time_branch_with_temporal_mlp():
+    """image/modeling_image.py:83-84,129-134: the image-family layer keeps a temporal MLP behind the temporal attention"""
+    _check_vision("image_time_tiny")
+
+
+@pytest.mark.parametrize("name", ["patch_dropout_tiny", "patch_dropout_video_tiny"])
+def test_patch_dropout_training_mode(name):
+    """image/modeling_image.py:30-63: the reference tower ran in training mode with force_patch_dropout > 0; the fixture holds the
+    kept-token indices its CPU randn / topk produced (recovered by re-seeding), the oracle takes them as an input"""
+    _check_vision(name)
+    fix = load_golden(name)
+    assert fix["last_hidden_state"].shape[1] == 1 + fix["patch_keep"].shape[1] < O.VisionCfg(**fix["cfg"]).seq_len
 
 
 def test_vision_s197_hd64():

@@ -234,8 +234,9 @@ def test_optimizer_state_exchanges_with_torch_adam(pkg):
     assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == list(range(len(list(model.parameters()))))
     names = [n for n, _ in model.named_parameters()]
     assert sd["param_groups"][0]["param_names"] == names
+    import copy
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
-    opt.load_state_dict(sd)                                   # torch accepts it as its own
+    opt.load_state_dict(copy.deepcopy(sd))                    # torch accepts it as its own (a copy: torch adopts the 'step' tensors and bumps them in place)
     used = 0
     for i, p in enumerate(model.parameters()):
         if i in sd["state"]:
