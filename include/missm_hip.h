@@ -230,6 +230,27 @@ int missm_lora_merge(float* W, int ldw, const float* A, const float* B, int n_ou
 int missm_lora_grad(const float* G, int ldg, const float* A, const float* B, float* dA, float* dB, int n_out, int k_in, int r, float scale,
                     void* stream);
 
+/* Audio front end (languagebind/audio/processing_audio.py:31-111).  All buffers are device fp32.
+ * buffer_mean   : out[0] = mean(x[0..n))  (`audio_data -= audio_data.mean()`, :96; fixed summation order)
+ * fbank_frames  : number of frames of an n-sample clip (snip_edges): 1 + (n - window) / shift, 0 if shorter than one window (host only)
+ * kaldi_fbank   : torchaudio.compliance.kaldi.fbank(wave - *global_mean, htk_compat=True, use_energy=False, window_type="hanning",
+ *                 dither=0, num_mel_bins, frame_length, frame_shift, sample_frequency; defaults: remove_dc_offset, preemphasis 0.97,
+ *                 round_to_power_of_two, power spectrum, log mel energies floored at float eps, low_freq 20, high_freq 0 = Nyquist)
+ *                 -> out [frames, num_mel_bins]  (:97-107)
+ * mel_assemble  : the three chunks starting at start0/1/2 (clip longer than target_length) or the clip tiled up to target_length
+ *                 (shorter / equal), transposed to out [3, num_mel_bins, target_length] and normalised (x - mean) / (2 std)  (:54-93)
+ * sinc_resample : torchaudio.functional.resample's strided convolution (:44-46): out[q * new + p] = sum_j kernels[p, j] *
+ *                 padded[q * orig + j]; `kernels` [new_freq, 2 width + orig_freq] is the windowed-sinc table (host-built, see
+ *                 missm_benchmark_amd/processing.py), orig_freq / new_freq already divided by their gcd. */
+int missm_buffer_mean(const float* x, long n, float* out, void* stream);
+int missm_fbank_frames(long n, float sample_rate, float frame_length_ms, float frame_shift_ms);
+int missm_kaldi_fbank(const float* wave, long n, const float* global_mean, float* out, int num_mel_bins, float sample_rate,
+                      float frame_length_ms, float frame_shift_ms, float low_freq, float high_freq, float preemphasis, void* stream);
+int missm_mel_assemble(const float* mel, int frames, int num_mel_bins, float* out, int target_length, int start0, int start1, int start2,
+                       float mean, float std, void* stream);
+int missm_sinc_resample(const float* wave, long n, const float* kernels, int kernel_len, int orig_freq, int new_freq, int width, float* out,
+                        long n_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -54,11 +54,16 @@ SIGNATURES = {
     "missm_adam_cast_batched": [P, I, L, L, L, I, F, F, F, F, F, F, I, P],
     "missm_lora_merge": [P, I, P, P, I, I, I, F, P],
     "missm_lora_grad": [P, I, P, P, P, P, I, I, I, F, P],
+    "missm_buffer_mean": [P, L, P, P],
+    "missm_kaldi_fbank": [P, L, P, P, I, F, F, F, F, F, F, P],
+    "missm_mel_assemble": [P, I, I, P, I, I, I, I, F, F, P],
+    "missm_sinc_resample": [P, L, P, I, I, I, I, P, L, P],
 }
 PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "missm_device_count": ([], I),
-         "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None)}
+         "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None),
+         "missm_fbank_frames": ([L, F, F, F], I)}
 
-ABI_VERSION = 8     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 9     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

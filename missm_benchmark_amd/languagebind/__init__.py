@@ -229,14 +229,17 @@ def _gpu_transform(kind):
         if kind == "depth":
             vc = (config or {}).get("vision_config", {}) if isinstance(config, dict) else {}
             return processing.DepthTransform(max_depth=float(vc.get("max_depth", 10)), **kw)
+        if kind == "audio":
+            return processing.AudioTransform(config, **kw)
         return processing.ImageTransform(**kw)
     return make
 
 
-# image / thermal / depth: GPU-side transforms (processing.py); video decoding and the audio filter bank are host libraries
-# that are not in this image - those entries raise
+# image / thermal / depth / audio: GPU-side transforms (processing.py); video decoding (decord / cv2 / pytorchvideo) is a host
+# library stack that is not in this image - that entry raises
 transform_dict = {m: _OutOfScope(f"{m} processor") for m in model_dict}
-transform_dict.update({"image": _gpu_transform("image"), "thermal": _gpu_transform("thermal"), "depth": _gpu_transform("depth")})
+transform_dict.update({"image": _gpu_transform("image"), "thermal": _gpu_transform("thermal"), "depth": _gpu_transform("depth"),
+                       "audio": _gpu_transform("audio")})
 LanguageBindImageTokenizer = _OutOfScope("LanguageBindImageTokenizer")
 
 

@@ -494,3 +494,42 @@ def lora_grad(g, a, b, da, db, scale):
             not (a.is_contiguous() and b.is_contiguous() and da.is_contiguous() and db.is_contiguous()):
         raise _lib.MissmError("lora_grad: g [n, k], a / da [r, k], b / db [n, r] (fp32, contiguous rows)")
     _lib.call("missm_lora_grad", g.data_ptr(), g.stride(0), a.data_ptr(), b.data_ptr(), da.data_ptr(), db.data_ptr(), n, k, r, float(scale), _s())
+
+
+def kaldi_fbank(wave, num_mel_bins, sample_rate, *, frame_length=25.0, frame_shift=10.0, low_freq=20.0, high_freq=0.0, preemphasis=0.97,
+                subtract_global_mean=True):
+    """wave: device fp32 [n] (one channel) -> log mel filter-bank energies [frames, num_mel_bins] (see include/missm_hip.h)"""
+    _req(wave, "kaldi_fbank wave")
+    if wave.dim() != 1 or wave.dtype != torch.float32 or not wave.is_contiguous():
+        raise _lib.MissmError("kaldi_fbank: wave must be a contiguous fp32 [n] tensor")
+    n = wave.numel()
+    frames = _lib.load().missm_fbank_frames(n, float(sample_rate), float(frame_length), float(frame_shift))
+    if frames <= 0:
+        raise _lib.MissmError("kaldi_fbank: waveform shorter than one frame")
+    gm = None
+    if subtract_global_mean:
+        gm = torch.empty(1, device=wave.device, dtype=torch.float32)
+        _lib.call("missm_buffer_mean", wave.data_ptr(), n, gm.data_ptr(), _s())
+    out = torch.empty(frames, num_mel_bins, device=wave.device, dtype=torch.float32)
+    _lib.call("missm_kaldi_fbank", wave.data_ptr(), n, _p(gm), out.data_ptr(), int(num_mel_bins), float(sample_rate), float(frame_length),
+              float(frame_shift), float(low_freq), float(high_freq), float(preemphasis), _s())
+    return out
+
+
+def mel_assemble(mel, target_length, starts, mean, std):
+    frames, nb = mel.shape
+    out = torch.empty(3, nb, target_length, device=mel.device, dtype=torch.float32)
+    _lib.call("missm_mel_assemble", mel.data_ptr(), frames, nb, out.data_ptr(), int(target_length), int(starts[0]), int(starts[1]), int(starts[2]),
+              float(mean), float(std), _s())
+    return out
+
+
+def sinc_resample(wave, kernels, orig_freq, new_freq, width, n_out):
+    """wave fp32 [n] -> fp32 [n_out]; kernels fp32 [new_freq, 2 * width + orig_freq] (frequencies already divided by their gcd)"""
+    _req(wave, "sinc_resample wave"); _req(kernels, "sinc_resample kernels")
+    if wave.dim() != 1 or kernels.dim() != 2 or kernels.shape[0] != new_freq or not kernels.is_contiguous() or wave.dtype != torch.float32:
+        raise _lib.MissmError("sinc_resample: wave [n] and kernels [new_freq, 2 width + orig_freq], fp32")
+    out = torch.empty(n_out, device=wave.device, dtype=torch.float32)
+    _lib.call("missm_sinc_resample", wave.data_ptr(), wave.numel(), kernels.data_ptr(), kernels.shape[1], int(orig_freq), int(new_freq), int(width),
+              out.data_ptr(), int(n_out), _s())
+    return out

@@ -78,7 +78,7 @@ def vision_fixture(name, modality, cfg: O.VisionCfg, batch, seed_w, seed_x, stor
     fix = {"cfg": cfg.__dict__.copy(), "seed_w": seed_w, "pixel_values": x, "last_hidden_state": last.detach(),
            "pooled": pooled.detach()}
     if keep is not None:
-        fix["patch_keep"] = keep
+        fix["patch_keep"], fix["patch_seed"] = keep, seed_x + 500
     if grad_names:
         cot_p = torch.randn(pooled.shape, generator=_gen(seed_x + 100))
         cot_h = torch.randn(last.shape, generator=_gen(seed_x + 101)) * 0.1

@@ -558,6 +558,92 @@ def depth_transform(depth_hw: Tensor, max_depth: float = 10.0, size: int = 224) 
     return image_transform(d[None].repeat(3, 1, 1), size)
 
 
+# ----------------------------------------------------------------------------
+# audio front end (languagebind/audio/processing_audio.py:31-111).  torchaudio is ABSENT from this image and unpinned upstream:
+# ``torchaudio.compliance.kaldi.fbank`` and ``torchaudio.functional.resample`` are restated here from their published algorithms in
+# plain torch - PARITY UNPINNED for these two (no reference run, no fixtures upstream); the reference's own code around them
+# (mean removal, chunking, normalisation) is followed line by line.
+# ----------------------------------------------------------------------------
+def kaldi_fbank(waveform: Tensor, sample_frequency: float, num_mel_bins: int, frame_length: float = 25.0, frame_shift: float = 10.0,
+                low_freq: float = 20.0, high_freq: float = 0.0, preemphasis_coefficient: float = 0.97) -> Tensor:
+    """``torchaudio.compliance.kaldi.fbank(waveform, htk_compat=True, sample_frequency=..., use_energy=False, window_type="hanning",
+    num_mel_bins=..., dither=0.0, frame_length=25, frame_shift=10)`` as called at processing_audio.py:97-107, remaining arguments at
+    their defaults (channel 0, snip_edges, remove_dc_offset, preemphasis 0.97, round_to_power_of_two, use_power, use_log_fbank,
+    energy_floor unused, no vtln warp): frames of ``waveform[0]`` -> DC removal -> pre-emphasis (first sample against itself) -> hann
+    window (non-periodic) -> zero pad to a power of two -> |rfft|^2 -> triangular mel filters (mel = 1127 ln(1 + f / 700), zero
+    weight on the Nyquist bin) -> log(max(., eps)).  Returns [frames, num_mel_bins]."""
+    wave = waveform[0] if waveform.dim() == 2 else waveform
+    window_shift = int(sample_frequency * 0.001 * frame_shift)
+    window_size = int(sample_frequency * 0.001 * frame_length)
+    padded = 1 << (window_size - 1).bit_length()
+    if wave.numel() < window_size:
+        return torch.empty(0, num_mel_bins)
+    m = 1 + (wave.numel() - window_size) // window_shift
+    frames = wave.as_strided((m, window_size), (window_shift, 1))
+    frames = frames - frames.mean(dim=1, keepdim=True)
+    prev = F.pad(frames.unsqueeze(0), (1, 0), mode="replicate").squeeze(0)[:, :-1]
+    frames = frames - preemphasis_coefficient * prev
+    frames = frames * torch.hann_window(window_size, periodic=False, dtype=frames.dtype).unsqueeze(0)
+    frames = F.pad(frames, (0, padded - window_size))
+    spectrum = torch.fft.rfft(frames).abs().pow(2.0)                               # [m, padded / 2 + 1]
+    nyquist = 0.5 * sample_frequency
+    if high_freq <= 0.0:
+        high_freq += nyquist
+    mel = lambda f: 1127.0 * math.log(1.0 + f / 700.0)                             # noqa: E731
+    mel_low, mel_high = mel(low_freq), mel(high_freq)
+    delta = (mel_high - mel_low) / (num_mel_bins + 1)
+    b = torch.arange(num_mel_bins, dtype=torch.float32).unsqueeze(1)
+    left, center, right = mel_low + b * delta, mel_low + (b + 1.0) * delta, mel_low + (b + 2.0) * delta
+    fft_mel = (1127.0 * (1.0 + (sample_frequency / padded) * torch.arange(padded // 2, dtype=torch.float32) / 700.0).log()).unsqueeze(0)
+    bank = torch.max(torch.zeros(1), torch.min((fft_mel - left) / (center - left), (right - fft_mel) / (right - center)))
+    bank = F.pad(bank, (0, 1))
+    energies = spectrum @ bank.T
+    return torch.max(energies, torch.tensor(torch.finfo(torch.float32).eps)).log()
+
+
+def sinc_resample(waveform: Tensor, orig_freq: int, new_freq: int, lowpass_filter_width: int = 6, rolloff: float = 0.99) -> Tensor:
+    """``torchaudio.functional.resample(waveform, orig_freq, new_freq)`` (processing_audio.py:46) with its defaults (``sinc_interp_hann``,
+    lowpass_filter_width 6, rolloff 0.99): a strided convolution with ``new`` windowed-sinc kernels (frequencies divided by their gcd)."""
+    g = math.gcd(int(orig_freq), int(new_freq))
+    orig, new = int(orig_freq) // g, int(new_freq) // g
+    base = min(orig, new) * rolloff
+    width = math.ceil(lowpass_filter_width * orig / base)
+    idx = torch.arange(-width, width + orig, dtype=torch.float64)[None, None] / orig
+    t = (torch.arange(0, -new, -1, dtype=torch.float64)[:, None, None] / new + idx) * base
+    t = t.clamp_(-lowpass_filter_width, lowpass_filter_width)
+    window = torch.cos(t * math.pi / lowpass_filter_width / 2) ** 2
+    t = t * math.pi
+    kernels = torch.where(t == 0, torch.tensor(1.0, dtype=torch.float64), t.sin() / t) * window * (base / orig)
+    kernels = kernels.to(torch.float32)
+    shape = waveform.shape
+    wave = waveform.reshape(-1, shape[-1])
+    length = wave.shape[1]
+    wave = F.pad(wave, (width, width + orig))
+    out = F.conv1d(wave[:, None], kernels, stride=orig).transpose(1, 2).reshape(wave.shape[0], -1)
+    target = int(math.ceil(new * length / orig))
+    return out[..., :target].reshape(shape[:-1] + (target,))
+
+
+def audio_transform(audio_data: Tensor, origin_sr: int, sample_rate: int, num_mel_bins: int, target_length: int, audio_mean: float,
+                    audio_std: float, starts: Optional[Sequence[int]] = None) -> Tensor:
+    """``AudioTransform.__call__`` / ``waveform2melspec`` / ``get_mel`` processing_audio.py:41-108.  ``starts``: the three chunk starts
+    (the reference draws them with ``np.random.choice``, :69-71); needed only when the clip has more than target_length frames."""
+    if sample_rate != origin_sr:
+        audio_data = sinc_resample(audio_data, origin_sr, sample_rate)
+    audio_data = audio_data - audio_data.mean()                                    # :96
+    mel = kaldi_fbank(audio_data, sample_rate, num_mel_bins)                       # (T, n_mels)
+    if mel.shape[0] > target_length:                                               # :56-77
+        mel_fusion = torch.stack([mel[s:s + target_length] for s in starts], dim=0)
+    elif mel.shape[0] < target_length:                                             # :78-82
+        n_repeat = int(target_length / mel.shape[0]) + 1
+        mel = mel.repeat(n_repeat, 1)[:target_length]
+        mel_fusion = torch.stack([mel, mel, mel], dim=0)
+    else:
+        mel_fusion = torch.stack([mel, mel, mel], dim=0)
+    mel_fusion = mel_fusion.transpose(1, 2)                                        # [3, mel_bins, target_length]
+    return (mel_fusion - audio_mean) / (audio_std * 2)                             # :92
+
+
 def kl_loss(g_s: Tensor, g_t: Tensor, temperature: float = 0.15) -> Tensor:
     """``KL_loss.forward`` train_ddp.py:70-79: kl_div(log_softmax(g_s / T), softmax(g_t.detach() / T), reduction='batchmean')."""
     return F.kl_div(F.log_softmax(g_s / temperature, dim=1), F.softmax(g_t.detach() / temperature, dim=1), reduction="batchmean")

@@ -105,12 +105,11 @@ def test_lora_tower_forward_backward_vs_oracle(pkg, case, dtype, tol):
     ch = torch.randn(last.shape, generator=torch.Generator().manual_seed(8)) * 0.1
     ((opooled * cp).sum() + (olast * ch).sum()).backward()
     ((pooled * cp.cuda()).sum() + (last * ch.cuda()).sum()).backward()
-    pub = _peft_keys({k: k for k in p}, ocfg)
-    inv = {v: k for k, v in pub.items()}
+    orig = _peft_keys({k: k for k in p}, ocfg)          # peft key -> the oracle's key
     for k, q in tower.named_parameters():
         if k in trainable:
             assert q.grad is not None, k
-            assert grad_ok(inv[k], q.grad, op[inv[k]].grad, tol * 4, dtype, fro_scale=2.0), k
+            assert grad_ok(orig[k], q.grad, op[orig[k]].grad, tol * 4, dtype, fro_scale=2.0), k
         else:
             assert q.grad is None, f"frozen {k} got a gradient"
     # a second backward before the gradients are consumed ADDS (autograd semantics), also for dA / dB derived from the scratch dW
@@ -131,9 +130,10 @@ def test_lora_adam_step_moves_only_the_trainable_tensors(pkg, case):
     tower = pkg.towers.ClipTower(T(kind="vision", **TINY, lora_r=2, lora_alpha=16.0, **CASES[case]), compute_dtype=torch.float32)
     tower.load_state_dict(_peft_keys(p, ocfg), strict=True)
     tower = tower.cuda()
-    pub = _peft_keys({k: k for k in p}, ocfg)
+    pub = {v: k for k, v in _peft_keys({k: k for k in p}, ocfg).items()}          # the oracle's key -> peft key
     x = _inputs(ocfg, 3, 9)
-    cp = torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
+    # (a large cotangent: Adam's first step is lr * g / (|g| + eps) - keep every |g| far above eps = 1e-8, where rounding would decide the sign)
+    cp = 1e3 * torch.randn(3, 64, generator=torch.Generator().manual_seed(10))
     eng = TrainEngine(tower, lr=1e-2)
     before = {k: v.detach().clone() for k, v in tower.state_dict().items()}
     eng.zero_grad()

@@ -261,3 +261,65 @@ def test_resize_pos_vs_reference():
     vc = _vision_config_from_json({"hidden_size": 64, "patch_size": fix["patch_size"], "num_mel_bins": fix["num_mel_bins"],
                                    "target_length": fix["target_length"], "image_size": 224})
     assert vc.image_hw == (fix["num_mel_bins"], fix["target_length"]) and vc.grid == tuple(fix["grid"]) and vc.seq_len == fix["new"].shape[0]
+
+
+def _np_fbank(wave, sr, nbins):
+    """independent float64 numpy statement of the same published algorithm (frames -> DC -> pre-emphasis -> hann -> |rfft|^2 -> mel)"""
+    import numpy as np
+    w = wave.double().numpy()
+    shift, size = int(sr * 0.01), int(sr * 0.025)
+    pad = 1 << (size - 1).bit_length()
+    m = 1 + (len(w) - size) // shift
+    out = np.zeros((m, nbins))
+    mel = lambda f: 1127.0 * np.log(1.0 + f / 700.0)        # noqa: E731
+    lo, hi = mel(20.0), mel(sr / 2)
+    d = (hi - lo) / (nbins + 1)
+    fm = mel(sr / pad * np.arange(pad // 2))
+    bank = np.zeros((nbins, pad // 2 + 1))
+    for b in range(nbins):
+        left, c, r = lo + b * d, lo + (b + 1) * d, lo + (b + 2) * d
+        bank[b, :pad // 2] = np.maximum(0.0, np.minimum((fm - left) / (c - left), (r - fm) / (r - c)))
+    win = 0.5 - 0.5 * np.cos(2 * np.pi * np.arange(size) / (size - 1))
+    for i in range(m):
+        fr = w[i * shift:i * shift + size].copy()
+        fr -= fr.mean()
+        fr = fr - 0.97 * np.concatenate([fr[:1], fr[:-1]])
+        spec = np.abs(np.fft.rfft(np.pad(fr * win, (0, pad - size)))) ** 2
+        out[i] = np.log(np.maximum(bank @ spec, np.finfo(np.float32).eps))
+    return out
+
+
+def test_audio_front_end_restatement_known_answers():
+    """kaldi fbank / sinc resample / AudioTransform of the oracle (torchaudio is absent and unpinned upstream: PARITY UNPINNED) against an
+    independent float64 numpy statement and known answers: a 1 kHz tone peaks in the mel bin whose centre is nearest 1 kHz, resampling
+    a band-limited tone reproduces the tone at the new rate, a short clip is tiled, chunks are cut where asked."""
+    import math
+    import numpy as np
+    sr, nb = 16000, 112
+    g = torch.Generator().manual_seed(0)
+    t = torch.arange(int(1.3 * sr)) / sr
+    wave = 0.4 * torch.sin(2 * math.pi * 1000.0 * t) + 0.01 * torch.randn(t.shape, generator=g)
+    mel = O.kaldi_fbank(wave[None], sr, nb)
+    assert mel.shape == (1 + (len(t) - 400) // 160, nb)
+    ref = _np_fbank(wave, sr, nb)
+    assert np.abs(mel.numpy() - ref).max() < 2e-3          # fp32 FFT / log of near-empty bins vs float64
+    centres = 700.0 * (np.exp((1127.0 * math.log(1 + 20 / 700.0) + (np.arange(nb) + 1) * (1127.0 * math.log(1 + 8000 / 700.0) - 1127.0 * math.log(1 + 20 / 700.0)) / (nb + 1)) / 1127.0) - 1.0)
+    assert int(mel.mean(0).argmax()) == int(np.abs(centres - 1000.0).argmin())
+    # resample 44.1 kHz -> 16 kHz: a 440 Hz tone stays a 440 Hz tone (away from the edges), length = ceil(new * n / orig)
+    n = 44100
+    x = torch.sin(2 * math.pi * 440.0 * torch.arange(n) / 44100.0)[None]
+    y = O.sinc_resample(x, 44100, 16000)
+    assert y.shape == (1, 16000)
+    want = torch.sin(2 * math.pi * 440.0 * torch.arange(16000) / 16000.0)
+    assert (y[0, 200:-200] - want[200:-200]).abs().max() < 2e-3
+    # AudioTransform: short clip tiled to target_length, normalised; long clip cut at the given starts
+    short = O.audio_transform(wave[None], sr, sr, nb, 300, -4.2677393, 4.5689974)
+    assert short.shape == (3, nb, 300) and torch.equal(short[0], short[1])
+    m = mel.shape[0]
+    mel_c = O.kaldi_fbank((wave - wave.mean())[None], sr, nb)           # (:96: the clip's mean is removed before the filter bank)
+    assert torch.allclose(short[0][:, m:2 * m], short[0][:, :m])       # tiled: mel.repeat(n)[:target_length]
+    assert torch.allclose(short[0][:, :m], (mel_c.T + 4.2677393) / (2 * 4.5689974), atol=1e-6)
+    long = O.audio_transform(wave[None], sr, sr, nb, 50, 0.5, 0.5, starts=(3, 30, 70))
+    w0 = wave - wave.mean()
+    mel0 = O.kaldi_fbank(w0[None], sr, nb)
+    assert torch.allclose(long[1], (mel0[30:80].T - 0.5) / 1.0, atol=1e-6)
