@@ -105,6 +105,15 @@ int missm_layernorm_fwd(const float* x, float* x_wb, const float* add, int add_d
 int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
                         const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate, float* dgamma,
                         float* dbeta, void* dx_cast, int rows, int cols, int dy_dtype, void* stream);
+/* The same two kernels for `ngroups` <= 8 shape-identical towers that run in lock-step (languagebind/__init__.py:75-85 encodes the
+ * modalities one after the other; missm_gemm_grouped): one launch, every operand an array of per-tower pointers.  Residual-stream
+ * form only: no row gather / additive vector; the backward accumulates into dx (+=) and writes the dy-dtype copy dx_cast; dgamma /
+ * dbeta (arrays or entries) may be null (frozen LayerNorms of a LoRA tower). */
+int missm_layernorm_fwd_grouped(int ngroups, const float* const* x, const float* const* gamma, const float* const* beta, void* const* y,
+                                float* const* mean, float* const* rstd, int rows, int cols, float eps, int out_dtype, void* stream);
+int missm_layernorm_bwd_grouped(int ngroups, const void* const* dy, const float* const* x, const float* const* mean, const float* const* rstd,
+                                const float* const* gamma, float* const* dx, float* const* dgamma, float* const* dbeta, void* const* dx_cast,
+                                int rows, int cols, int dy_dtype, void* stream);
 /* out[b] = mean_t in[b*T + t]   (pooled_output.reshape(B, T, -1).mean(1), image/modeling_image.py:662). */
 int missm_mean_rows(const float* in, float* out, int B, int T, int cols, void* stream);
 

@@ -470,12 +470,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(GemmArgs gall) {
 
   const int ntiles = gall.tiles_m * gall.tiles_n;
   const int per_group = ntiles * gall.splitk;
-  const int gi = blockIdx.x / per_group, bid = blockIdx.x - gi * per_group;     // grouped launch: group-major workgroup ids
+  int gi, split, tix, tm, tn;
   GemmArgs g = gall;
-  if (gall.ngroups > 1) select_group(g, gall, gi);
-  const int split = bid / ntiles, tix = bid - split * ntiles;
-  int tm, tn;
-  tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  if (gall.tn_order == 1) {                   // XCD-contiguous (group, K slice, tile row, tile column): see GemmArgs::tn_order
+    const int logical = xcd_remap(blockIdx.x, per_group * gall.ngroups);
+    gi = logical / per_group;
+    const int rem = logical - gi * per_group;
+    split = rem / ntiles; tix = rem - split * ntiles;
+    tm = tix / gall.tiles_n; tn = tix - tm * gall.tiles_n;
+    if (gall.ngroups > 1) select_group(g, gall, gi);
+  } else {
+    gi = blockIdx.x / per_group;
+    const int bid = blockIdx.x - gi * per_group;   // grouped launch: group-major workgroup ids
+    if (gall.ngroups > 1) select_group(g, gall, gi);
+    split = bid / ntiles; tix = bid - split * ntiles;
+    tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  }
   const int m0 = tm * 256, n0 = tn * 256;
   const int kbeg = split * g.k_per_split;
   const int kend = min(g.K, kbeg + g.k_per_split);
@@ -688,7 +698,8 @@ __global__ __launch_bounds__(512) void splitk_reduce8p_kernel(GemmArgs gall) {
   if (gall.ngroups > 1) select_group(g, gall, gi);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wr = wave >> 2, wc = wave & 3, li = lane & 15, lg = lane >> 4;
   int tm, tn;
-  tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
+  if (gall.tn_order == 1) { tm = tix / g.tiles_n; tn = tix - tm * g.tiles_n; }
+  else tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
   const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + ((size_t)gi * ntiles * g.splitk + tix) * (32 * 512) + (size_t)(4 * e) * 512 + tid;
   f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
   for (int sl = 0; sl < g.splitk; ++sl, p += (size_t)ntiles * (32 * 512)) {

@@ -30,9 +30,9 @@ struct LnFwdArgs {
 };
 
 template <typename Tout, int CH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
+__device__ __forceinline__ void ln_fwd_body(const LnFwdArgs& a, int bx) {
   const int lane = threadIdx.x & 63;
-  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int row = bx * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
   const float* xr = a.x + irow * a.cols;
@@ -82,6 +82,21 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) {
   }
 }
 
+template <typename Tout, int CH>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) { ln_fwd_body<Tout, CH>(a, blockIdx.x); }
+
+// Grouped launch: the same LayerNorm site of several shape-identical towers that run in lock-step (towers.forward_lanes) - one grid,
+// blockIdx.y selects the tower's pointers (four 6304-row launches of 9-20 us each were latency, not bandwidth).
+constexpr int LN_MAX_GROUPS = 8;
+struct LnFwdGroups { const float* x[LN_MAX_GROUPS]; const float* gamma[LN_MAX_GROUPS]; const float* beta[LN_MAX_GROUPS]; void* y[LN_MAX_GROUPS];
+                     float* mean[LN_MAX_GROUPS]; float* rstd[LN_MAX_GROUPS]; };
+template <typename Tout, int CH>
+__global__ __launch_bounds__(256) void ln_fwd_grouped_kernel(LnFwdArgs a, LnFwdGroups gs) {
+  const int g = blockIdx.y;
+  a.x = gs.x[g]; a.gamma = gs.gamma[g]; a.beta = gs.beta[g]; a.y = gs.y[g]; a.mean = gs.mean[g]; a.rstd = gs.rstd[g];
+  ln_fwd_body<Tout, CH>(a, blockIdx.x);
+}
+
 struct LnBwdArgs {
   const void* dy;        // Tin rows ; dy row = row / dy_div ; scaled by dy_scale
   int dy_div; float dy_scale;
@@ -98,8 +113,8 @@ struct LnBwdArgs {
 // FAST: cols == CH * 256, accumulate, dx_cast and no row gather - the residual-stream LayerNorms of every tower layer.  With the
 // column guards and the uniform branches gone the loop is straight-line code, so the compiler can COUNT the memory operations:
 // it waits for the prefetched row with vmcnt(#stores issued after it) instead of vmcnt(0) on the stores' write acknowledgements.
-template <typename Tin, int CH, bool FAST = false>
-__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
+template <typename Tin, int CH, bool FAST>
+__device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) {
   __shared__ float red[2][4][CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   f32x4 ag[CH], ab[CH];
@@ -135,7 +150,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     }
     nmean = a.mean[row]; nrstd = a.rstd[row];
   };
-  const int row0 = blockIdx.x * 4 + wave, rstep = gridDim.x * 4;
+  const int row0 = bx * 4 + wave, rstep = gx * 4;
   if (row0 < a.rows) issue(row0);
   for (int row = row0; row < a.rows; row += rstep) {
     const size_t irow = (size_t)row * a.in_mul + ((!FAST && a.in_off) ? a.in_off[row] : 0);
@@ -193,6 +208,20 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) {
     if (a.dgamma) atomicAdd(a.dgamma + col, sg);
     if (a.dbeta) atomicAdd(a.dbeta + col, sb);
   }
+}
+
+template <typename Tin, int CH, bool FAST = false>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) { ln_bwd_body<Tin, CH, FAST>(a, blockIdx.x, gridDim.x); }
+
+struct LnBwdGroups { const void* dy[LN_MAX_GROUPS]; const float* x[LN_MAX_GROUPS]; const float* mean[LN_MAX_GROUPS]; const float* rstd[LN_MAX_GROUPS];
+                     const float* gamma[LN_MAX_GROUPS]; float* dx[LN_MAX_GROUPS]; float* dgamma[LN_MAX_GROUPS]; float* dbeta[LN_MAX_GROUPS];
+                     void* dx_cast[LN_MAX_GROUPS]; };
+template <typename Tin, int CH, bool FAST>
+__global__ __launch_bounds__(256) void ln_bwd_grouped_kernel(LnBwdArgs a, LnBwdGroups gs) {
+  const int g = blockIdx.y;
+  a.dy = gs.dy[g]; a.x = gs.x[g]; a.mean = gs.mean[g]; a.rstd = gs.rstd[g]; a.gamma = gs.gamma[g]; a.dx = gs.dx[g];
+  a.dgamma = gs.dgamma[g]; a.dbeta = gs.dbeta[g]; a.dx_cast = gs.dx_cast[g];
+  ln_bwd_body<Tin, CH, FAST>(a, blockIdx.x, gridDim.x);
 }
 
 // mean over groups of T consecutive rows: out[b] = mean_t in[b*T + t]  (pooled.reshape(B,T,-1).mean(1), :662)
@@ -262,6 +291,55 @@ extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, c
   });
   if (rc != MISSM_OK) return rc;
   return missm_check_launch("layernorm_bwd");
+}
+
+extern "C" int missm_layernorm_fwd_grouped(int ngroups, const float* const* x, const float* const* gamma, const float* const* beta, void* const* y,
+                                           float* const* mean, float* const* rstd, int rows, int cols, float eps, int out_dtype, void* stream) {
+  MISSM_CHECK_ARG(ngroups >= 1 && ngroups <= LN_MAX_GROUPS && x && gamma && beta && y && mean && rstd, "layernorm_fwd_grouped: 1..8 groups");
+  MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_fwd_grouped: cols must be a positive multiple of 4");
+  LnFwdArgs a{nullptr, nullptr, nullptr, 1, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, cols, eps};
+  LnFwdGroups gs;
+  for (int g = 0; g < ngroups; ++g) { gs.x[g] = x[g]; gs.gamma[g] = gamma[g]; gs.beta[g] = beta[g]; gs.y[g] = y[g]; gs.mean[g] = mean[g]; gs.rstd[g] = rstd[g]; }
+  dim3 grid((rows + 3) / 4, ngroups), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = dispatch_ch<void>(cols, [&](auto ch) {
+    constexpr int CH = decltype(ch)::value;
+    if (out_dtype == kBF16) hipLaunchKernelGGL((ln_fwd_grouped_kernel<bf16, CH>), grid, block, 0, s, a, gs);
+    else hipLaunchKernelGGL((ln_fwd_grouped_kernel<float, CH>), grid, block, 0, s, a, gs);
+    return MISSM_OK;
+  });
+  if (rc != MISSM_OK) return rc;
+  return missm_check_launch("layernorm_fwd_grouped");
+}
+
+extern "C" int missm_layernorm_bwd_grouped(int ngroups, const void* const* dy, const float* const* x, const float* const* mean,
+                                           const float* const* rstd, const float* const* gamma, float* const* dx, float* const* dgamma,
+                                           float* const* dbeta, void* const* dx_cast, int rows, int cols, int dy_dtype, void* stream) {
+  MISSM_CHECK_ARG(ngroups >= 1 && ngroups <= LN_MAX_GROUPS && dy && x && mean && rstd && gamma && dx && dx_cast, "layernorm_bwd_grouped: 1..8 groups");
+  MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd_grouped: cols must be a positive multiple of 4");
+  LnBwdArgs a{nullptr, 1, 1.0f, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, rows, cols, nullptr};
+  LnBwdGroups gs;
+  for (int g = 0; g < ngroups; ++g) {
+    gs.dy[g] = dy[g]; gs.x[g] = x[g]; gs.mean[g] = mean[g]; gs.rstd[g] = rstd[g]; gs.gamma[g] = gamma[g]; gs.dx[g] = dx[g];
+    gs.dgamma[g] = dgamma ? dgamma[g] : nullptr; gs.dbeta[g] = dbeta ? dbeta[g] : nullptr; gs.dx_cast[g] = dx_cast[g];
+    MISSM_CHECK_ARG(gs.dx_cast[g] != nullptr, "layernorm_bwd_grouped: every group needs dx_cast (the residual-stream form)");
+  }
+  static const int cap = getenv("MISSM_LN_BLOCKS") ? atoi(getenv("MISSM_LN_BLOCKS")) : 512;
+  int blocks = (rows + 3) / 4;
+  const int per = cap / ngroups > 0 ? cap / ngroups : 1;        // the cap is for the whole launch
+  if (blocks > per) blocks = per;
+  dim3 grid(blocks, ngroups), block(256);
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  int rc = dispatch_ch<void>(cols, [&](auto ch) {
+    constexpr int CH = decltype(ch)::value;
+    const bool fast = cols == CH * 256;
+    if (dy_dtype == kBF16 && fast) hipLaunchKernelGGL((ln_bwd_grouped_kernel<bf16, CH, true>), grid, block, 0, s, a, gs);
+    else if (dy_dtype == kBF16) hipLaunchKernelGGL((ln_bwd_grouped_kernel<bf16, CH, false>), grid, block, 0, s, a, gs);
+    else hipLaunchKernelGGL((ln_bwd_grouped_kernel<float, CH, false>), grid, block, 0, s, a, gs);
+    return MISSM_OK;
+  });
+  if (rc != MISSM_OK) return rc;
+  return missm_check_launch("layernorm_bwd_grouped");
 }
 
 extern "C" int missm_mean_rows(const float* in, float* out, int B, int T, int cols, void* stream) {

@@ -200,6 +200,30 @@ def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, cols, *, ac
     return dx
 
 
+def _ptrs(lst):
+    import ctypes as C
+    return (C.c_void_p * len(lst))(*[None if t is None else t.data_ptr() for t in lst])
+
+
+def layernorm_fwd_lanes(xs, gammas, betas, ys, means, rstds, rows, cols, eps):
+    """the same LayerNorm of several lock-step towers: one launch for two or more lanes, `layernorm_fwd` for one"""
+    if len(xs) == 1:
+        return layernorm_fwd(xs[0], gammas[0], betas[0], ys[0], means[0], rstds[0], rows, cols, eps)
+    _lib.call("missm_layernorm_fwd_grouped", len(xs), _ptrs(xs), _ptrs(gammas), _ptrs(betas), _ptrs(ys), _ptrs(means), _ptrs(rstds), rows, cols,
+              float(eps), dt(ys[0]), _s())
+
+
+def layernorm_bwd_lanes(dys, xs, means, rstds, gammas, dxs, dgammas, dbetas, rows, cols, dx_casts):
+    """residual-stream backward (accumulate into dx, dy-dtype copy to dx_cast) of several lock-step towers in one launch"""
+    if len(dys) == 1:
+        return layernorm_bwd(dys[0], xs[0], means[0], rstds[0], gammas[0], dxs[0], dgammas[0], dbetas[0], rows, cols, accumulate=True,
+                             dx_cast=dx_casts[0])
+    if any(c.dtype != dys[0].dtype for c in dx_casts):
+        raise _lib.MissmError("layernorm_bwd_lanes: dx_cast must have dy's dtype")
+    _lib.call("missm_layernorm_bwd_grouped", len(dys), _ptrs(dys), _ptrs(xs), _ptrs(means), _ptrs(rstds), _ptrs(gammas), _ptrs(dxs), _ptrs(dgammas),
+              _ptrs(dbetas), _ptrs(dx_casts), rows, cols, dt(dys[0]), _s())
+
+
 def cast_rows(x, out, R, C, rdiv=0, roff=0):
     _lib.call("missm_cast_rows", x.data_ptr(), out.data_ptr(), R, C, rdiv, roff, dt(out), _s())
     return out

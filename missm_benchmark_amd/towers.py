@@ -697,8 +697,7 @@ def forward_lanes(towers, inputs, save: bool):
                 # so the '(b t) n d <-> (b n) t d' rearrangements around them change nothing
                 xm = E(rows, d, device=dev, dtype=T)
                 mm, rm = E(rows, **f32), E(rows, **f32)
-                for g in G:
-                    ops.layernorm_fwd(h[g], L[g].tln2_w, L[g].tln2_b, xm[g], mm[g], rm[g], rows, d, c.layer_norm_eps)
+                ops.layernorm_fwd_lanes(h, [l.tln2_w for l in L], [l.tln2_b for l in L], xm, mm, rm, rows, d, c.layer_norm_eps)
                 at = E(rows, f, device=dev, dtype=T)
                 ut = E(rows, f, device=dev, dtype=T) if save else None
                 ops.gemm_grouped(xm, W(f"{pfx}.tfc1", 0), at, bias=[l.tfc1_b for l in L], act=act, aux_out=ut)
@@ -710,8 +709,7 @@ def forward_lanes(towers, inputs, save: bool):
                 h = h3
         x1 = E(rows, d, device=dev, dtype=T)
         m1, r1 = E(rows, **f32), E(rows, **f32)
-        for g in G:
-            ops.layernorm_fwd(h[g], L[g].ln1_w, L[g].ln1_b, x1[g], m1[g], r1[g], rows, d, c.layer_norm_eps)
+        ops.layernorm_fwd_lanes(h, [l.ln1_w for l in L], [l.ln1_b for l in L], x1, m1, r1, rows, d, c.layer_norm_eps)
         # (the lanes' QKV / context / log-sum-exp buffers are slices of ONE allocation: the sequences of all lanes are one
         #  attention launch - four 384-(frame, head) launches fill 512 workgroup slots to 75 % each, one 1536-unit launch runs
         #  three full rounds in which one workgroup's K / V fetch overlaps another's arithmetic)
@@ -727,8 +725,7 @@ def forward_lanes(towers, inputs, save: bool):
         ops.gemm_grouped(ctx, W(f"{pfx}.out", 0), h2, bias=[l.out_b for l in L], resid=h)
         x2 = E(rows, d, device=dev, dtype=T)
         m2, r2 = E(rows, **f32), E(rows, **f32)
-        for g in G:
-            ops.layernorm_fwd(h2[g], L[g].ln2_w, L[g].ln2_b, x2[g], m2[g], r2[g], rows, d, c.layer_norm_eps)
+        ops.layernorm_fwd_lanes(h2, [l.ln2_w for l in L], [l.ln2_b for l in L], x2, m2, r2, rows, d, c.layer_norm_eps)
         a = E(rows, f, device=dev, dtype=T)
         u = E(rows, f, device=dev, dtype=T) if save else None
         ops.gemm_grouped(x2, W(f"{pfx}.fc1", 0), a, bias=[l.fc1_b for l in L], act=act, aux_out=u)
@@ -824,8 +821,7 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
         _linear_bwd_lanes(towers, dh_T, a, W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], rows, dx_outs=du, act=dact, aux_ins=u, lora_sites=LS("fc2"))
         dx2 = E(rows, d, device=dev, dtype=T)
         _linear_bwd_lanes(towers, du, x2, W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], rows, dx_outs=dx2, lora_sites=LS("fc1"))
-        for g in G:
-            ops.layernorm_bwd(dx2[g], h2[g], m2[g], r2[g], L[g].ln2_w, dh[g], L[g].g_ln2_w, L[g].g_ln2_b, rows, d, accumulate=True, dx_cast=dh_T[g])
+        ops.layernorm_bwd_lanes(dx2, h2, m2, r2, [l.ln2_w for l in L], dh, [l.g_ln2_w for l in L], [l.g_ln2_b for l in L], rows, d, dh_T)
         # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
         hin, x1, m1, r1, qkv, ctx, lse = (list(v) for v in zip(*[r.a for r in recs]))
         dctx_all = torch.empty(rows * len(towers), d, device=dev, dtype=T)
@@ -841,16 +837,14 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
             ops.attention_bwd(qkv[0], ctx[0], dctx[0], lse[0], dqkv[0], N, S, H, hd, causal=states[0].causal, key_mask=states[0].key_mask)
         dx1 = E(rows, d, device=dev, dtype=T)
         _linear_bwd_lanes(towers, dqkv, x1, W(f"{pfx}.qkv", 1), [l.g_qkv_w for l in L], [l.g_qkv_b for l in L], rows, dx_outs=dx1, lora_sites=LS("qkv"))
-        for g in G:
-            ops.layernorm_bwd(dx1[g], hin[g], m1[g], r1[g], L[g].ln1_w, dh[g], L[g].g_ln1_w, L[g].g_ln1_b, rows, d, accumulate=True, dx_cast=dh_T[g])
+        ops.layernorm_bwd_lanes(dx1, hin, m1, r1, [l.ln1_w for l in L], dh, [l.g_ln1_w for l in L], [l.g_ln1_b for l in L], rows, d, dh_T)
         if c.temporal_mlp:
             hin, xm, mm, rm, ut, at = (list(v) for v in zip(*[r.tm for r in recs]))
             dut = E(rows, f, device=dev, dtype=T)
             _linear_bwd_lanes(towers, dh_T, at, W(f"{pfx}.tfc2", 1), [l.g_tfc2_w for l in L], [l.g_tfc2_b for l in L], rows, dx_outs=dut, act=dact, aux_ins=ut, lora_sites=LS("tfc2"))
             dxm = E(rows, d, device=dev, dtype=T)
             _linear_bwd_lanes(towers, dut, xm, W(f"{pfx}.tfc1", 1), [l.g_tfc1_w for l in L], [l.g_tfc1_b for l in L], rows, dx_outs=dxm, lora_sites=LS("tfc1"))
-            for g in G:
-                ops.layernorm_bwd(dxm[g], hin[g], mm[g], rm[g], L[g].tln2_w, dh[g], L[g].g_tln2_w, L[g].g_tln2_b, rows, d, accumulate=True, dx_cast=dh_T[g])
+            ops.layernorm_bwd_lanes(dxm, hin, mm, rm, [l.tln2_w for l in L], dh, [l.g_tln2_w for l in L], [l.g_tln2_b for l in L], rows, d, dh_T)
         if c.add_time_attn:
             hin, xt, mt, rt, qkv, ctx, lse = (list(v) for v in zip(*[r.t for r in recs]))
             dctx = E(rows, d, device=dev, dtype=T)

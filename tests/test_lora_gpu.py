@@ -44,7 +44,7 @@ def _params(cfg, seed):
     g = torch.Generator().manual_seed(seed + 1)
     for stem, n_out, k_in in _targets(cfg):
         p[stem + ".lora_A.default.weight"] = torch.randn(cfg.lora_r, k_in, generator=g) * 0.2
-        p[stem + ".lora_B.default.weight"] = torch.randn(n_out, cfg.lora_r, generator=g) * 0.2
+        p[stem + ".lora_B.default.weight"] = torch.randn(n_out, cfg.lora_r, generator=g) * 0.02      # (alpha / r) B A ~ the base weight's size
     return p
 
 
