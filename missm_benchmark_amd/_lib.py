@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmissm_hip.so")
+LIB_PATH = os.environ.get("MISSM_LIB_PATH") or os.path.join(_HERE, "libmissm_hip.so")     # (MISSM_LIB_PATH: A/B runs against an experiment build)
 
 P, I, F, L, U64 = C.c_void_p, C.c_int, C.c_float, C.c_long, C.c_ulonglong
 

@@ -3,15 +3,17 @@
 set -euo pipefail
 cd "$(dirname "$0")"
 HIPCC=${HIPCC:-/opt/rocm/bin/hipcc}
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result"
-mkdir -p ../_build
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result ${EXTRA:-}"
+OUT=${OUT:-libmissm_hip.so}        # (EXTRA / OUT: experiment builds next to the product library, loaded through MISSM_LIB_PATH)
+BUILD=../_build${EXTRA:+_exp}
+mkdir -p $BUILD
 pids=()
 for f in gemm layernorm attention misc lora audio; do
-  ( $HIPCC $FLAGS -c $f.hip -o ../_build/$f.o ${SAVE_TEMPS:+-save-temps=obj} ) &
+  ( $HIPCC $FLAGS -c $f.hip -o $BUILD/$f.o ${SAVE_TEMPS:+-save-temps=obj} ) &
   pids+=($!)
 done
-( $HIPCC $FLAGS -c capi.cpp -o ../_build/capi.o ) &
+( $HIPCC $FLAGS -c capi.cpp -o $BUILD/capi.o ) &
 pids+=($!)
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../libmissm_hip.so ../_build/gemm.o ../_build/layernorm.o ../_build/attention.o ../_build/misc.o ../_build/lora.o ../_build/audio.o ../_build/capi.o
-echo "built $(realpath ../libmissm_hip.so)"
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o ../$OUT $BUILD/gemm.o $BUILD/layernorm.o $BUILD/attention.o $BUILD/misc.o $BUILD/lora.o $BUILD/audio.o $BUILD/capi.o
+echo "built $(realpath ../$OUT)"

@@ -812,10 +812,46 @@ template <typename T>
 __global__ __launch_bounds__(256) void adam_cast_batched_kernel(const CastTile* __restrict__ tiles, AdamTileArgs a) {
   __shared__ float tile[64][65];
   const CastTile t = tiles[blockIdx.x];
-  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   float* src = const_cast<float*>(t.src);
   T* dst = static_cast<T*>(t.dst);
   T* dst_t = static_cast<T*>(t.dst_t);
+  if ((t.C & 3) == 0 && (t.R & 3) == 0 && ((uintptr_t)src & 15) == 0 && ((a.g_off | a.m_off | a.v_off) & 3) == 0) {
+    // [r3] 16-byte accesses: a thread owns 4 consecutive columns of a row (16 threads per row, 16 rows per pass) - the scalar version
+    // (4 bytes per lane: 256 bytes per wave instruction) moved the 32 bytes per parameter at 4.1 TB/s.  Same arithmetic per element.
+    const int tc = (threadIdx.x & 15) * 4, tr = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int rl = tr + 16 * i, r = t.r0 + rl, c = t.c0 + tc;
+      f32x4 pv = {0.f, 0.f, 0.f, 0.f};
+      if (r < t.R && c < t.C) {
+        float* p = src + (size_t)r * t.C + c;
+        pv = load4(p);
+        const f32x4 gv = load4(p + a.g_off);
+        f32x4 mv = load4(p + a.m_off), vv = load4(p + a.v_off);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float gg = gv[j] * a.gscale + a.wd * pv[j];
+          mv[j] = a.beta1 * mv[j] + (1.f - a.beta1) * gg;
+          vv[j] = a.beta2 * vv[j] + (1.f - a.beta2) * gg * gg;
+          pv[j] -= a.lr_bc1 * mv[j] / (sqrtf(vv[j]) * a.inv_sqrt_bc2 + a.eps);
+        }
+        store4(p, pv); store4(p + a.m_off, mv); store4(p + a.v_off, vv);
+        if (dst) store4(dst + (size_t)r * t.C + c, pv);
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tile[rl][tc + j] = pv[j];
+    }
+    if (!dst_t) return;
+    __syncthreads();
+    // transposed copy: a thread owns 4 consecutive ROWS (= 4 consecutive elements of a W^T row) of one column
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int cl = tr + 16 * i, c = t.c0 + cl, r = t.r0 + tc;
+      if (c < t.C && r < t.R) store4(dst_t + (size_t)c * t.R + r, f32x4{tile[tc][cl], tile[tc + 1][cl], tile[tc + 2][cl], tile[tc + 3][cl]});
+    }
+    return;
+  }
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < 16; ++i) {
     const int r = t.r0 + ty + 4 * i, c = t.c0 + tx;
@@ -1009,7 +1045,7 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
     }
     log_shape(M);
     hipLaunchKernelGGL(kt, dim3(g.ngroups * t2 * sp), dim3(512), 128 * 1024, s, g);
-    hipLaunchKernelGGL(splitk_reduce8p_kernel, dim3(g.ngroups * t2 * 8), dim3(512), 0, s, g);
+    hipLaunchKernelGGL(splitk_reduce8p_kernel, dim3(g.ngroups * t2 * 16), dim3(512), 0, s, g);
     return missm_check_launch("gemm8p_tn");
   }
   if (ngroups > 1 && (trans_a || trans_b)) return MISSM_GROUPED_UNAVAILABLE;

@@ -92,6 +92,11 @@ __device__ __forceinline__ void gemm8p_prologue(char* lds, const Gemm8pSrc& src,
 // ---------------------------------------------------------------------------------------------------------------------
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+// cache policy of the epilogue's C / aux stores (buffer aux bits: 0 default, 2 = nt, 16 = sc1: write-through that does not keep the line
+// in the XCD's L2).  A build-time knob for A/B runs (csrc/build.sh EXTRA=-DMISSM_EPI_AUX=16 OUT=libmissm_hip_sc1.so).
+#ifndef MISSM_EPI_AUX
+#define MISSM_EPI_AUX 0
+#endif
 
 struct Epi8p {
   __amdgpu_buffer_rsrc_t c, aux, res;
@@ -144,7 +149,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
         const f32x4 uu = unpack_bf16x4(u[ch & 1][k]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(uu[j]);
-        __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), 0);
+        __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), MISSM_EPI_AUX);
       }
     }
   } else if constexpr (MODE == 3) {
@@ -163,7 +168,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
         for (int r = 0; r < 4; ++r) {
           f32x4 v = MISSM_VAL(ch >> 2, ch & 3, r);
           v += __builtin_bit_cast(f32x4, q[ch & 1][r]);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ch >> 2, ch & 3), 0);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ch >> 2, ch & 3), MISSM_EPI_AUX);
         }
       }
     } else {
@@ -174,7 +179,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const f32x4 v = MISSM_VAL(ha, i, r);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ha, i), 0);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ha, i), MISSM_EPI_AUX);
           }
     }
   } else {
@@ -186,11 +191,11 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
         for (int r = 0; r < 4; ++r) {
           f32x4 v = MISSM_VAL(ha, i, r);
           if constexpr (MODE == 1) {
-            if (has_aux) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.aux, var[r], MISSM_SA(ha, i), 0);
+            if (has_aux) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.aux, var[r], MISSM_SA(ha, i), MISSM_EPI_AUX);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), 0);
+          __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), MISSM_EPI_AUX);
         }
   }
 #undef MISSM_VAL
@@ -687,12 +692,15 @@ __global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(GemmArgs gall) {
         for (int j = 0; j < 2; ++j) mine[(((a * 2 + b) * 4 + i) * 2 + j) * 512] = acc[a][b][i][j];
 }
 
-// sums the K slices of gemm8p_tn_kernel in slice order.  One workgroup per (tile, eighth): thread t adds up vectors
-// v = 4 e .. 4 e + 3 of every slice and stores its 16 elements: rows m0 + 128 ha + 64 wr + 16 i + 4 lg + r, column
-// n0 + 128 hb + 32 wc + 16 j + li  (16 consecutive columns per lane group: 64-byte runs)
+// sums the K slices of gemm8p_tn_kernel in slice order.  One workgroup per (tile, sixteenth): thread t adds up vectors
+// v = 2 e, 2 e + 1 of every slice and stores its 8 elements: rows m0 + 128 ha + 64 wr + 16 i + 4 lg + r, column
+// n0 + 128 hb + 32 wc + 16 j + li  (16 consecutive columns per lane group: 64-byte runs).
+// [r3] 16 workgroups per tile instead of 8 and the slice loop unrolled by four: the first version (27 tiles x 8 = 216 workgroups on
+// 256 CUs, four loads in flight per thread) read the parked slices at 3.6 TB/s - latency-, not bandwidth-bound.  The sum over the
+// slices still runs in slice order (the unrolled loads are added one after the other): results are bit-identical.
 __global__ __launch_bounds__(512) void splitk_reduce8p_kernel(GemmArgs gall) {
   const int ntiles = gall.tiles_m * gall.tiles_n;
-  const int gt = blockIdx.x >> 3, e = blockIdx.x & 7;
+  const int gt = blockIdx.x >> 4, e = blockIdx.x & 15;
   const int gi = gt / ntiles, tix = gt - gi * ntiles;
   GemmArgs g = gall;
   if (gall.ngroups > 1) select_group(g, gall, gi);
@@ -700,16 +708,27 @@ __global__ __launch_bounds__(512) void splitk_reduce8p_kernel(GemmArgs gall) {
   int tm, tn;
   if (gall.tn_order == 1) { tm = tix / g.tiles_n; tn = tix - tm * g.tiles_n; }
   else tile_of(xcd_remap(tix, ntiles), g.tiles_m, g.tiles_n, g.group_m, tm, tn);
-  const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + ((size_t)gi * ntiles * g.splitk + tix) * (32 * 512) + (size_t)(4 * e) * 512 + tid;
-  f32x4 a[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
-  for (int sl = 0; sl < g.splitk; ++sl, p += (size_t)ntiles * (32 * 512)) {
+  const size_t stride = (size_t)ntiles * (32 * 512);
+  const f32x4* p = reinterpret_cast<const f32x4*>(g.ws) + ((size_t)gi * ntiles * g.splitk + tix) * (32 * 512) + (size_t)(2 * e) * 512 + tid;
+  f32x4 a[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+  int sl = 0;
+  for (; sl + 4 <= g.splitk; sl += 4, p += 4 * stride) {
+    f32x4 x[4][2];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) a[v] += __builtin_nontemporal_load(p + v * 512);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int v = 0; v < 2; ++v) x[u][v] = __builtin_nontemporal_load(p + u * stride + v * 512);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { a[0] += x[u][0]; a[1] += x[u][1]; }
+  }
+  for (; sl < g.splitk; ++sl, p += stride) {
+#pragma unroll
+    for (int v = 0; v < 2; ++v) a[v] += __builtin_nontemporal_load(p + v * 512);
   }
   float* C = static_cast<float*>(g.C);
 #pragma unroll
-  for (int v = 0; v < 4; ++v) {
-    const int vv = 4 * e + v, j = vv & 1, i = (vv >> 1) & 3, hb = (vv >> 3) & 1, ha = vv >> 4;
+  for (int v = 0; v < 2; ++v) {
+    const int vv = 2 * e + v, j = vv & 1, i = (vv >> 1) & 3, hb = (vv >> 3) & 1, ha = vv >> 4;
     const int col = tn * 256 + 128 * hb + 32 * wc + 16 * j + li;
     if (col >= g.N) continue;
 #pragma unroll
