@@ -14,6 +14,7 @@
 // V^T fragments come from ds_read_b64_tr_b16 on the row-major V tile.  The backward runs two passes inside one
 // launch (query-on-lane for dQ, key-on-lane for dK/dV), re-staging LDS in between; D = rowsum(P o dP) is
 // formed in registers, so O is not needed and nothing is accumulated with atomics.
+#include <stdlib.h>
 #include "common.h"
 #include "mma.h"
 #include "missm_internal.h"
@@ -1155,6 +1156,225 @@ __global__ __launch_bounds__(64) void attn_small_bwd_kernel(AttnArgs a, int hd) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Time attention of the video tower (L = T <= 8 tokens per sequence, head_dim 64, not causal): [r3] a dedicated pair of kernels.
+// The per-wave instantiation of the kernels above (NTP = 2) spent a 32-row K and a 32-row V tile on 8 real rows (six of every eight
+// LDS-DMA pieces fetched zeros), held one (sequence, head) unit per wave and - in the backward - made two dependent memory round trips
+// (K / V for the dQ pass, then Q / dO for the dK / dV pass): 3.8 / 3.2 TB/s, bound by the latency of short-lived waves.
+// Here a wave owns a PAIR of units: rows 0-7 of every 16-row tile belong to unit 2p, rows 8-15 to unit 2p + 1, and the 16 x 16 score
+// tile is block-diagonal (a key and a query of different units never meet: -inf).  Every operand tile holds real rows only (one 1-KiB
+// LDS-DMA piece per unit and matrix in bf16), the backward stages K, V, Q and dO up front (ONE round trip), and the second half of the
+// 32-deep bf16 MFMA step - keys 16-31, which do not exist - is a literal zero operand instead of zero rows in LDS.  Twice the units
+// in flight per CU at a fifth of the LDS.
+// ---------------------------------------------------------------------------------------------------
+template <typename T, int RB> struct TrHalf;     // C-as-operand A fragment over rows 0-15 only (the step's rows 16-31 are zeros)
+template <int RB> struct TrHalf<bf16, RB> {
+  __device__ static __forceinline__ bf16x8 load(const char* lds, int c0, int lane) {
+    const int i = lane & 15, g = lane >> 4, q = i >> 2, p = i & 3;
+    const char* a0 = lds + swz<RB>(4 * g + q, (c0 + 4 * p) * 2);
+    i16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((i16x4 __attribute__((address_space(3)))*)(a0));
+    using i16x8 = __attribute__((ext_vector_type(8))) short;
+    i16x8 v = {lo[0], lo[1], lo[2], lo[3], 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8, v);
+  }
+};
+template <int RB> struct TrHalf<float, RB> {
+  __device__ static __forceinline__ f32x4 load(const char* lds, int c0, int lane) { return TrFrag<float, RB>::load(lds, 0, c0, lane); }
+};
+template <typename T> __device__ __forceinline__ typename Mma<T>::Frag acc_lo(f32x4 t) { return Mma<T>::from_acc(t, f32x4{0.f, 0.f, 0.f, 0.f}); }
+
+struct TimeUnit { size_t base; int seq, h; bool ok; };
+__device__ __forceinline__ TimeUnit time_unit(const AttnArgs& a, int unit) {
+  TimeUnit u;
+  u.ok = unit < a.nseq * a.H;
+  u.seq = u.ok ? unit / a.H : 0; u.h = u.ok ? unit % a.H : 0;
+  u.base = seq_base(a, u.seq);
+  return u;
+}
+
+template <typename T>
+__global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 8 : 4) void attn_time_fwd_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T), KSQ = HD / M_::KS;
+  constexpr int SLICE = 2 * 16 * RBv;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  const int pair = blockIdx.x * ANW + wave;
+  if (2 * pair >= a.nseq * a.H) return;       // (wave-uniform: the transposed LDS reads below need every lane)
+  char* ldsK = smem_all + wave * SLICE;
+  char* ldsV = ldsK + 16 * RBv;
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const int L = a.L;
+  const TimeUnit u0 = time_unit(a, 2 * pair), u1 = time_unit(a, 2 * pair + 1);
+  stage_head<T, RBv, 1>(ldsK, qkv, u0.base, a.tok_stride, a.ld, a.d + u0.h * HD, L, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsK + 8 * RBv, qkv, u1.base, a.tok_stride, a.ld, a.d + u1.h * HD, u1.ok ? L : 0, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsV, qkv, u0.base, a.tok_stride, a.ld, 2 * a.d + u0.h * HD, L, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsV + 8 * RBv, qkv, u1.base, a.tok_stride, a.ld, 2 * a.d + u1.h * HD, u1.ok ? L : 0, 8, lane, 0);
+  // this lane's query: unit li >> 3 of the pair, token li & 7
+  const bool second = li >= 8;
+  const TimeUnit& uq = second ? u1 : u0;
+  const int tq = li & 7;
+  const bool qvalid = uq.ok && tq < L;
+  const size_t qrow = uq.base + (size_t)(qvalid ? tq : 0) * a.tok_stride;
+  Frag qf[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) {
+    qf[ks] = M_::zero();
+    if (qvalid) qf[ks] = *reinterpret_cast<const Frag*>(qkv + qrow * a.ld + uq.h * HD + ks * M_::KS + lg * M_::KPL);
+  }
+  // validity of the four keys 4 lg + r this lane meets: same unit as the query, a real token, not masked
+  bool kok[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int tk = 4 * (lg & 1) + r;
+    kok[r] = qvalid && (lg >> 1) == (li >> 3) && tk < L && (!a.key_mask || a.key_mask[(size_t)uq.seq * L + tk] != 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const float sl2 = a.scale * 1.4426950408889634f;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) acc = M_::step(lds_frag<T>(ldsK, swz<RBv>(li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T))), qf[ks], acc);
+  float mx = kNegInf;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] = kok[r] ? acc[r] : kNegInf; mx = fmaxf(mx, acc[r]); }
+  mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+  mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+  if (mx == kNegInf) mx = 0.f;
+  const float mxs = mx * sl2;
+  float sum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) { acc[r] = __builtin_amdgcn_exp2f(acc[r] * sl2 - mxs); sum += acc[r]; }
+  const Frag pf = acc_lo<T>(acc);
+  // (the row sum is taken from the ROUNDED probabilities that multiply V, like the ones-row of the big kernel)
+  if constexpr (sizeof(T) == 2) { sum = 0.f; _Pragma("unroll") for (int r = 0; r < 4; ++r) sum += (float)pf[r]; }
+  sum += __shfl_xor(sum, 16, 64);
+  sum += __shfl_xor(sum, 32, 64);
+  const float inv = 1.0f / sum;
+  if (a.lse && qvalid && lg == 0) a.lse[((size_t)uq.seq * a.H + uq.h) * L + tq] = (mxs + __log2f(sum)) * 0.6931471805599453f;
+  T* out = static_cast<T*>(a.out);
+#pragma unroll
+  for (int dt = 0; dt < HD / 16; ++dt) {
+    f32x4 o = M_::step(TrHalf<T, RBv>::load(ldsV, dt * 16, lane), pf, f32x4{0.f, 0.f, 0.f, 0.f});
+    o *= inv;
+    if (qvalid) store4(out + qrow * a.ldo + uq.h * HD + dt * 16 + 4 * lg, o);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(ATHREADS, sizeof(T) == 2 ? 4 : 2) void attn_time_bwd_kernel(AttnArgs a) {
+  using M_ = Mma<T>;
+  using Frag = typename M_::Frag;
+  constexpr int RBv = HD * sizeof(T), KSQ = HD / M_::KS;
+  constexpr int SLICE = 4 * 16 * RBv + 2 * 16 * 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_all[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), li = lane & 15, lg = lane >> 4;
+  const int pair = blockIdx.x * ANW + wave;
+  if (2 * pair >= a.nseq * a.H) return;
+  char* ldsK = smem_all + wave * SLICE;
+  char* ldsV = ldsK + 16 * RBv;
+  char* ldsQ = ldsV + 16 * RBv;
+  char* ldsG = ldsQ + 16 * RBv;               // dO
+  float* lseL = reinterpret_cast<float*>(ldsG + 16 * RBv);
+  float* Dl = lseL + 16;
+  const T* qkv = static_cast<const T*>(a.qkv);
+  const T* dout = static_cast<const T*>(a.dout);
+  const T* fout = static_cast<const T*>(a.out);
+  T* dqkv = static_cast<T*>(a.dqkv);
+  const int L = a.L;
+  const TimeUnit u0 = time_unit(a, 2 * pair), u1 = time_unit(a, 2 * pair + 1);
+  const int L1 = u1.ok ? L : 0;
+  stage_head<T, RBv, 1>(ldsK, qkv, u0.base, a.tok_stride, a.ld, a.d + u0.h * HD, L, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsK + 8 * RBv, qkv, u1.base, a.tok_stride, a.ld, a.d + u1.h * HD, L1, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsV, qkv, u0.base, a.tok_stride, a.ld, 2 * a.d + u0.h * HD, L, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsV + 8 * RBv, qkv, u1.base, a.tok_stride, a.ld, 2 * a.d + u1.h * HD, L1, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsQ, qkv, u0.base, a.tok_stride, a.ld, u0.h * HD, L, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsQ + 8 * RBv, qkv, u1.base, a.tok_stride, a.ld, u1.h * HD, L1, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsG, dout, u0.base, a.tok_stride, a.ldo, u0.h * HD, L, 8, lane, 0);
+  stage_head<T, RBv, 1>(ldsG + 8 * RBv, dout, u1.base, a.tok_stride, a.ldo, u1.h * HD, L1, 8, lane, 0);
+  // this lane's row li of the pair tile (a query in pass A, a key in pass B): unit li >> 3, token li & 7
+  const bool second = li >= 8;
+  const TimeUnit& um = second ? u1 : u0;
+  const int tm = li & 7;
+  const bool mvalid = um.ok && tm < L;
+  const size_t mrow = um.base + (size_t)(mvalid ? tm : 0) * a.tok_stride;
+  // D = rowsum(dO . O) of this lane's query from the saved forward output (the same number as sum_j P dP), lse / scale alongside
+  float dsum = 0.f;
+  if (mvalid) {
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks)
+      dsum = frag_dot(*reinterpret_cast<const Frag*>(dout + mrow * a.ldo + um.h * HD + ks * M_::KS + lg * M_::KPL),
+                      *reinterpret_cast<const Frag*>(fout + mrow * a.ldo + um.h * HD + ks * M_::KS + lg * M_::KPL), dsum);
+  }
+  dsum += __shfl_xor(dsum, 16, 64);
+  dsum += __shfl_xor(dsum, 32, 64);
+  const float inv_scale = 1.0f / a.scale;
+  const float lq = mvalid ? a.lse[((size_t)um.seq * a.H + um.h) * L + tm] * inv_scale : __builtin_huge_valf();
+  if (lg == 0) { lseL[li] = lq; Dl[li] = dsum; }
+  const bool kmask_ok = mvalid && (!a.key_mask || a.key_mask[(size_t)um.seq * L + tm] != 0);   // pass B: this lane's key
+  bool kokA[4];                                 // pass A: the four keys 4 lg + r against this lane's query
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int tk = 4 * (lg & 1) + r;
+    kokA[r] = mvalid && (lg >> 1) == (li >> 3) && tk < L && (!a.key_mask || a.key_mask[(size_t)um.seq * L + tk] != 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  const float sl2 = a.scale * 1.4426950408889634f;
+  int off[KSQ];
+#pragma unroll
+  for (int ks = 0; ks < KSQ; ++ks) off[ks] = swz<RBv>(li, (ks * M_::KS + lg * M_::KPL) * (int)sizeof(T));
+
+  // ---------------- pass A: query on the lane -> dQ ----------------
+  {
+    f32x4 sc = {-lq, -lq, -lq, -lq}, dp = {-dsum, -dsum, -dsum, -dsum};
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      sc = M_::step(lds_frag<T>(ldsK, off[ks]), lds_frag<T>(ldsQ, off[ks]), sc);
+      dp = M_::step(lds_frag<T>(ldsV, off[ks]), lds_frag<T>(ldsG, off[ks]), dp);
+    }
+    f32x4 ds;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) ds[r] = kokA[r] ? __builtin_amdgcn_exp2f(sc[r] * sl2) * dp[r] : 0.f;
+    const Frag dsf = acc_lo<T>(ds);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      f32x4 dq = M_::step(TrHalf<T, RBv>::load(ldsK, dt * 16, lane), dsf, f32x4{0.f, 0.f, 0.f, 0.f});
+      dq *= a.scale;
+      if (mvalid) store4(dqkv + mrow * a.ld + um.h * HD + dt * 16 + 4 * lg, dq);
+    }
+  }
+  // ---------------- pass B: key on the lane -> dK, dV ----------------
+  {
+    f32x4 sc = -*reinterpret_cast<const f32x4*>(lseL + 4 * lg);
+    f32x4 dp = -*reinterpret_cast<const f32x4*>(Dl + 4 * lg);
+#pragma unroll
+    for (int ks = 0; ks < KSQ; ++ks) {
+      sc = M_::step(lds_frag<T>(ldsQ, off[ks]), lds_frag<T>(ldsK, off[ks]), sc);
+      dp = M_::step(lds_frag<T>(ldsG, off[ks]), lds_frag<T>(ldsV, off[ks]), dp);
+    }
+    f32x4 pv, ds;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      // query 4 lg + r of the tile: same unit as this lane's key (lse = +inf already zeroes queries that do not exist)
+      const bool ok = kmask_ok && (lg >> 1) == (li >> 3);
+      pv[r] = ok ? __builtin_amdgcn_exp2f(sc[r] * sl2) : 0.f;
+      ds[r] = pv[r] * dp[r];
+    }
+    const Frag pf = acc_lo<T>(pv), dsf = acc_lo<T>(ds);
+#pragma unroll
+    for (int dt = 0; dt < HD / 16; ++dt) {
+      f32x4 dv = M_::step(TrHalf<T, RBv>::load(ldsG, dt * 16, lane), pf, f32x4{0.f, 0.f, 0.f, 0.f});
+      f32x4 dk = M_::step(TrHalf<T, RBv>::load(ldsQ, dt * 16, lane), dsf, f32x4{0.f, 0.f, 0.f, 0.f});
+      dk *= a.scale;
+      if (mvalid) {
+        store4(dqkv + mrow * a.ld + a.d + um.h * HD + dt * 16 + 4 * lg, dk);
+        store4(dqkv + mrow * a.ld + 2 * a.d + um.h * HD + dt * 16 + 4 * lg, dv);
+      }
+    }
+  }
+}
+
 }  // namespace missm
 
 using namespace missm;
@@ -1179,6 +1399,22 @@ int fill_args(AttnArgs& a, const void* qkv, void* out, float* lse, const void* d
 
 template <typename T, bool BWD> int launch_attn(const AttnArgs& a, int hd, hipStream_t s) {
   const int L = a.L;
+  static const int use_time = getenv("MISSM_ATTN_TIME") ? atoi(getenv("MISSM_ATTN_TIME")) : 1;
+  if (use_time && L <= 8 && hd == HD && !a.causal) {   // the video tower's time attention: two (sequence, head) units per wave
+    const int pairs = (a.nseq * a.H + 1) / 2;
+    dim3 grid((pairs + ANW - 1) / ANW), block(ATHREADS);
+    const size_t shmem = (size_t)ANW * (BWD ? 4 * 16 * HD * sizeof(T) + 2 * 16 * 4 : 2 * 16 * HD * sizeof(T));
+    if constexpr (BWD) {
+      auto k = attn_time_bwd_kernel<T>;
+      int rc = launch_dyn(k, grid, block, shmem, s, "attn_time_bwd"); if (rc) return rc;
+      hipLaunchKernelGGL(k, grid, block, shmem, s, a);
+    } else {
+      auto k = attn_time_fwd_kernel<T>;
+      int rc = launch_dyn(k, grid, block, shmem, s, "attn_time_fwd"); if (rc) return rc;
+      hipLaunchKernelGGL(k, grid, block, shmem, s, a);
+    }
+    return missm_check_launch("attn_time");
+  }
   if (L <= 32 && hd == HD) {   // time attention / short text: one wave per (sequence, head) on the MFMA path
     constexpr int NTP = 2;
     const int units = a.nseq * a.H;

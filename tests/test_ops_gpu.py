@@ -348,6 +348,12 @@ CASES = [  # name, nseq-structure
     dict(name="spatial_s5", B=3, T=1, S=5, H=2, hd=32, temporal=False, causal=False, mask=False),
     dict(name="temporal_t8", B=2, T=8, S=7, H=3, hd=64, temporal=True, causal=False, mask=False),
     dict(name="temporal_t4", B=2, T=4, S=5, H=2, hd=32, temporal=True, causal=False, mask=False),
+    # the dedicated time-attention kernels (L <= 8, head_dim 64: two (sequence, head) units per wave, block-diagonal score tile):
+    # an odd unit count (the last pair is half empty), fewer than 8 tokens with a key mask, more than one workgroup of pairs, T = 1
+    dict(name="time_t8_odd_units", B=1, T=8, S=3, H=3, hd=64, temporal=True, causal=False, mask=False),
+    dict(name="time_t5_mask", B=2, T=5, S=3, H=1, hd=64, temporal=True, causal=False, mask=True),
+    dict(name="time_t8_many", B=3, T=8, S=11, H=4, hd=64, temporal=True, causal=False, mask=True),
+    dict(name="time_t1", B=2, T=1, S=7, H=2, hd=64, temporal=True, causal=False, mask=False),
     dict(name="text_s16", B=5, T=1, S=16, H=2, hd=32, temporal=False, causal=True, mask=True),
     dict(name="text_s32", B=3, T=1, S=32, H=2, hd=64, temporal=False, causal=True, mask=True),
     dict(name="mfma_s197", B=3, T=1, S=197, H=2, hd=64, temporal=False, causal=False, mask=False),
