@@ -412,7 +412,11 @@ def test_attention_fwd_bwd(ops, dtype, case):
     dqkv = torch.zeros(rows, 3 * d, device="cuda", dtype=dtype)
     ops.attention_bwd(QKV, out, dev(dout, dtype), lse, dqkv, nseq, L, H, hd, causal=case["causal"], key_mask=km, **kw)
     for i, nm in enumerate("qkv"):
-        assert rel(dqkv[:, i * d:(i + 1) * d], x.grad[:, i * d:(i + 1) * d]) < TOL[dtype] * 1.5, nm
+        ref = x.grad[:, i * d:(i + 1) * d]
+        if float(ref.abs().max()) == 0.0:     # L = 1: softmax over one key - dq and dk are identically zero, what comes back is rounding residue
+            assert float(dqkv[:, i * d:(i + 1) * d].float().abs().max()) < TOL[dtype] * 1.5, nm
+            continue
+        assert rel(dqkv[:, i * d:(i + 1) * d], ref) < TOL[dtype] * 1.5, nm
 
 
 # ------------------------------------------------------------------ embeddings / tail / loss / optimizer
