@@ -92,10 +92,12 @@ __device__ __forceinline__ void gemm8p_prologue(char* lds, const Gemm8pSrc& src,
 // ---------------------------------------------------------------------------------------------------------------------
 using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
 using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-// cache policy of the epilogue's C / aux stores (buffer aux bits: 0 default, 2 = nt, 16 = sc1: write-through that does not keep the line
-// in the XCD's L2).  A build-time knob for A/B runs (csrc/build.sh EXTRA=-DMISSM_EPI_AUX=16 OUT=libmissm_hip_sc1.so).
+// Cache policy of the epilogue's C / aux stores (buffer aux bits: 0 default, 2 = nt, 16 = sc1 = write-through that does not keep the
+// line in the XCD's L2).  Round 2 measured nt (worse on the whole step); round 3 measured sc1 against the default in alternating runs on
+// one box: 66.93 / 66.98 vs 67.07 / 67.36 ms per step (+0.35 %) - the outputs are far larger than L2 and are next read by another
+// kernel, keeping their lines in L2 only evicts operand panels.  (EXTRA=-DMISSM_EPI_AUX=<n> builds another policy for A/B runs.)
 #ifndef MISSM_EPI_AUX
-#define MISSM_EPI_AUX 0
+#define MISSM_EPI_AUX 16
 #endif
 
 struct Epi8p {

@@ -29,61 +29,82 @@ struct LnFwdArgs {
   int rows, cols; float eps;
 };
 
+// [r3] Grid-stride over the rows with a one-row look-ahead (like the backward): the first version ran one row per wave and exited -
+// 12 608 four-row workgroups per video launch, each paying its own launch and a load -> reduce -> reduce -> store chain with nothing
+// else in flight (4.6 TB/s).  gamma / beta are loaded once per wave.  The look-ahead is guarded (row + step < rows): every index
+// tensor (in_off) is read for valid rows only - the lesson of the round-2 abort.
 template <typename Tout, int CH>
-__device__ __forceinline__ void ln_fwd_body(const LnFwdArgs& a, int bx) {
+__device__ __forceinline__ void ln_fwd_body(const LnFwdArgs& a, int bx, int gx) {
   const int lane = threadIdx.x & 63;
-  const int row = bx * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
-  const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
-  const float* xr = a.x + irow * a.cols;
-  f32x4 v[CH];
-  float s = 0.f;
+  const int row0 = bx * 4 + (threadIdx.x >> 6), rstep = gx * 4;
+  if (row0 >= a.rows) return;
+  f32x4 gm[CH], bt[CH];
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
     const int col = (c * 64 + lane) * 4;
-    if (col < a.cols) {
-      v[c] = load4(xr + col);
-      if (a.add) {
-        f32x4 t = load4(a.add + (size_t)((row / a.div) % a.mod) * a.cols + col);
-        v[c] += t;
-        store4(a.x_wb + irow * a.cols + col, v[c]);
+    gm[c] = col < a.cols ? load4(a.gamma + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    bt[c] = col < a.cols ? load4(a.beta + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 nv[CH];
+  auto issue = [&](int row) {
+    const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
+    const float* xr = a.x + irow * a.cols;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      nv[c] = col < a.cols ? load4(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  issue(row0);
+  for (int row = row0; row < a.rows; row += rstep) {
+    const size_t irow = (size_t)row * a.in_mul + (a.in_off ? a.in_off[row] : 0);
+    f32x4 v[CH];
+    float s = 0.f;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      v[c] = nv[c];
+      if (col < a.cols) {
+        if (a.add) {
+          f32x4 t = load4(a.add + (size_t)((row / a.div) % a.mod) * a.cols + col);
+          v[c] += t;
+          store4(a.x_wb + irow * a.cols + col, v[c]);
+        }
+        s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
       }
-      s += v[c][0] + v[c][1] + v[c][2] + v[c][3];
-    } else {
-      v[c] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-  }
-  const float mean = wave_sum(s) / a.cols;
-  float q = 0.f;
+    if (row + rstep < a.rows) issue(row + rstep);
+    const float mean = wave_sum(s) / a.cols;
+    float q = 0.f;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int col = (c * 64 + lane) * 4;
-    if (col < a.cols) {
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < a.cols) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mean; q += d * d; }
+        for (int j = 0; j < 4; ++j) { const float d = v[c][j] - mean; q += d * d; }
+      }
     }
-  }
-  const float rstd = rsqrtf(wave_sum(q) / a.cols + a.eps);
-  if (lane == 0) {
-    if (a.mean) a.mean[row] = mean;
-    if (a.rstd) a.rstd[row] = rstd;
-  }
-  Tout* yr = static_cast<Tout*>(a.y) + (size_t)row * a.cols;
+    const float rstd = rsqrtf(wave_sum(q) / a.cols + a.eps);
+    if (lane == 0) {
+      if (a.mean) a.mean[row] = mean;
+      if (a.rstd) a.rstd[row] = rstd;
+    }
+    Tout* yr = static_cast<Tout*>(a.y) + (size_t)row * a.cols;
 #pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int col = (c * 64 + lane) * 4;
-    if (col < a.cols) {
-      const f32x4 gm = load4(a.gamma + col), bt = load4(a.beta + col);
-      f32x4 o;
+    for (int c = 0; c < CH; ++c) {
+      const int col = (c * 64 + lane) * 4;
+      if (col < a.cols) {
+        f32x4 o;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * gm[j] + bt[j];
-      store4(yr + col, o);
+        for (int j = 0; j < 4; ++j) o[j] = (v[c][j] - mean) * rstd * gm[c][j] + bt[c][j];
+        store4(yr + col, o);
+      }
     }
   }
 }
 
 template <typename Tout, int CH>
-__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) { ln_fwd_body<Tout, CH>(a, blockIdx.x); }
+__global__ __launch_bounds__(256) void ln_fwd_kernel(LnFwdArgs a) { ln_fwd_body<Tout, CH>(a, blockIdx.x, gridDim.x); }
 
 // Grouped launch: the same LayerNorm site of several shape-identical towers that run in lock-step (towers.forward_lanes) - one grid,
 // blockIdx.y selects the tower's pointers (four 6304-row launches of 9-20 us each were latency, not bandwidth).
@@ -94,7 +115,7 @@ template <typename Tout, int CH>
 __global__ __launch_bounds__(256) void ln_fwd_grouped_kernel(LnFwdArgs a, LnFwdGroups gs) {
   const int g = blockIdx.y;
   a.x = gs.x[g]; a.gamma = gs.gamma[g]; a.beta = gs.beta[g]; a.y = gs.y[g]; a.mean = gs.mean[g]; a.rstd = gs.rstd[g];
-  ln_fwd_body<Tout, CH>(a, blockIdx.x);
+  ln_fwd_body<Tout, CH>(a, blockIdx.x, gridDim.x);
 }
 
 struct LnBwdArgs {
@@ -255,7 +276,8 @@ extern "C" int missm_layernorm_fwd(const float* x, float* x_wb, const float* add
   MISSM_CHECK_ARG(!add || (x_wb && add_div > 0 && add_mod > 0), "layernorm_fwd: add needs x_wb, div, mod");
   LnFwdArgs a{x, x_wb, add, add_div > 0 ? add_div : 1, add_mod > 0 ? add_mod : 1, in_mul > 0 ? in_mul : 1, in_off, gamma, beta,
               y, mean, rstd, rows, cols, eps};
-  dim3 grid((rows + 3) / 4), block(256);
+  static const int fcap = getenv("MISSM_LN_FWD_BLOCKS") ? atoi(getenv("MISSM_LN_FWD_BLOCKS")) : 2048;   // 8 workgroups per CU, rows grid-strided
+  dim3 grid((rows + 3) / 4 < fcap ? (rows + 3) / 4 : fcap), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_ch<void>(cols, [&](auto ch) {
     constexpr int CH = decltype(ch)::value;
@@ -300,7 +322,9 @@ extern "C" int missm_layernorm_fwd_grouped(int ngroups, const float* const* x, c
   LnFwdArgs a{nullptr, nullptr, nullptr, 1, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, cols, eps};
   LnFwdGroups gs;
   for (int g = 0; g < ngroups; ++g) { gs.x[g] = x[g]; gs.gamma[g] = gamma[g]; gs.beta[g] = beta[g]; gs.y[g] = y[g]; gs.mean[g] = mean[g]; gs.rstd[g] = rstd[g]; }
-  dim3 grid((rows + 3) / 4, ngroups), block(256);
+  static const int fcap = getenv("MISSM_LN_FWD_BLOCKS") ? atoi(getenv("MISSM_LN_FWD_BLOCKS")) : 2048;
+  const int per = fcap / ngroups > 0 ? fcap / ngroups : 1;
+  dim3 grid((rows + 3) / 4 < per ? (rows + 3) / 4 : per, ngroups), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_ch<void>(cols, [&](auto ch) {
     constexpr int CH = decltype(ch)::value;
