@@ -29,10 +29,11 @@ struct LnFwdArgs {
   int rows, cols; float eps;
 };
 
-// [r3] Grid-stride over the rows with a one-row look-ahead (like the backward): the first version ran one row per wave and exited -
-// 12 608 four-row workgroups per video launch, each paying its own launch and a load -> reduce -> reduce -> store chain with nothing
-// else in flight (4.6 TB/s).  gamma / beta are loaded once per wave.  The look-ahead is guarded (row + step < rows): every index
-// tensor (in_off) is read for valid rows only - the lesson of the round-2 abort.
+// [r3] The rows can be grid-strided with a one-row look-ahead like the backward (MISSM_LN_FWD_BLOCKS caps the grid).  Measured inside
+// the step (alternating runs on one box): one row per wave - 12 608 four-row workgroups per video launch, the default - 67.18 / 67.20 ms,
+// capped at 1024 / 2048 / 4096 workgroups 67.31 / 67.40 / 67.28 ms: the forward is not latency-bound the way the backward was (8 waves
+// per SIMD already keep 96 KB per CU in flight), so the cap stays off.  gamma / beta are loaded once per wave.  The look-ahead is guarded
+// (row + step < rows): every index tensor (in_off) is read for valid rows only - the lesson of the round-2 abort.
 template <typename Tout, int CH>
 __device__ __forceinline__ void ln_fwd_body(const LnFwdArgs& a, int bx, int gx) {
   const int lane = threadIdx.x & 63;
@@ -276,7 +277,7 @@ extern "C" int missm_layernorm_fwd(const float* x, float* x_wb, const float* add
   MISSM_CHECK_ARG(!add || (x_wb && add_div > 0 && add_mod > 0), "layernorm_fwd: add needs x_wb, div, mod");
   LnFwdArgs a{x, x_wb, add, add_div > 0 ? add_div : 1, add_mod > 0 ? add_mod : 1, in_mul > 0 ? in_mul : 1, in_off, gamma, beta,
               y, mean, rstd, rows, cols, eps};
-  static const int fcap = getenv("MISSM_LN_FWD_BLOCKS") ? atoi(getenv("MISSM_LN_FWD_BLOCKS")) : 2048;   // 8 workgroups per CU, rows grid-strided
+  static const int fcap = getenv("MISSM_LN_FWD_BLOCKS") ? atoi(getenv("MISSM_LN_FWD_BLOCKS")) : (1 << 30);   // default: no cap (one row per wave)
   dim3 grid((rows + 3) / 4 < fcap ? (rows + 3) / 4 : fcap), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
   int rc = dispatch_ch<void>(cols, [&](auto ch) {
@@ -322,7 +323,7 @@ extern "C" int missm_layernorm_fwd_grouped(int ngroups, const float* const* x, c
   LnFwdArgs a{nullptr, nullptr, nullptr, 1, 1, 1, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, rows, cols, eps};
   LnFwdGroups gs;
   for (int g = 0; g < ngroups; ++g) { gs.x[g] = x[g]; gs.gamma[g] = gamma[g]; gs.beta[g] = beta[g]; gs.y[g] = y[g]; gs.mean[g] = mean[g]; gs.rstd[g] = rstd[g]; }
-  static const int fcap = getenv("MISSM_LN_FWD_BLOCKS") ? atoi(getenv("MISSM_LN_FWD_BLOCKS")) : 2048;
+  static const int fcap = getenv("MISSM_LN_FWD_BLOCKS") ? atoi(getenv("MISSM_LN_FWD_BLOCKS")) : (1 << 30);
   const int per = fcap / ngroups > 0 ? fcap / ngroups : 1;
   dim3 grid((rows + 3) / 4 < per ? (rows + 3) / 4 : per, ngroups), block(256);
   hipStream_t s = static_cast<hipStream_t>(stream);
