@@ -105,6 +105,13 @@ int missm_layernorm_fwd(const float* x, float* x_wb, const float* add, int add_d
 int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
                         const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate, float* dgamma,
                         float* dbeta, void* dx_cast, int rows, int cols, int dy_dtype, void* stream);
+/* missm_layernorm_bwd (no row gather, dy_div 1) that also accumulates GROUP SUMS of the updated dx rows:
+ * gsum[(row / gs_div) % gs_mod][:] += dx[row][:] (atomics; caller zeroes), rows = frames x gs_div.  Replaces the separate column-sum
+ * pass of the temporal-embedding gradient: `hidden_states + self.temporal_embedding[:, :t, :]` (image/modeling_image.py:114-116) puts
+ * d temporal_embedding[t] = sum over (b, n) of the residual gradient behind temporal_layer_norm1 (gs_div = S tokens, gs_mod = T). */
+int missm_layernorm_bwd_groupsum(const void* dy, float dy_scale, const float* x, const float* mean, const float* rstd,
+                                 const float* gamma, float* dx, int accumulate, float* dgamma, float* dbeta, void* dx_cast,
+                                 float* gsum, int gs_div, int gs_mod, int rows, int cols, int dy_dtype, void* stream);
 /* The same two kernels for `ngroups` <= 8 shape-identical towers that run in lock-step (languagebind/__init__.py:75-85 encodes the
  * modalities one after the other; missm_gemm_grouped): one launch, every operand an array of per-tower pointers.  Residual-stream
  * form only: no row gather / additive vector; the backward accumulates into dx (+=) and writes the dy-dtype copy dx_cast; dgamma /

@@ -24,6 +24,7 @@ SIGNATURES = {
     "missm_layernorm_fwd": [P, P, P, I, I, I, P, P, P, P, P, P, I, I, F, I, P],
     "missm_layernorm_bwd": [P, I, F, P, I, P, P, P, P, P, I, P, P, P, I, I, I, P],
     "missm_layernorm_fwd_grouped": [I, P, P, P, P, P, P, I, I, F, I, P],
+    "missm_layernorm_bwd_groupsum": [P, F, P, P, P, P, P, I, P, P, P, P, I, I, I, I, I, P],
     "missm_layernorm_bwd_grouped": [I, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "missm_cast_rows": [P, P, L, I, I, I, I, P],
     "missm_mean_rows": [P, P, I, I, I, P],
@@ -65,7 +66,7 @@ PLAIN = {"missm_last_error": ([], C.c_char_p), "missm_abi_version": ([], I), "mi
          "missm_gemm_set_debug_buffer": ([P], None), "missm_gemm_release_workspaces": ([], None),
          "missm_fbank_frames": ([L, F, F, F], I)}
 
-ABI_VERSION = 10     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
+ABI_VERSION = 11     # bumped with every signature change in include/missm_hip.h (capi.cpp: missm_abi_version)
 _lib = None
 
 

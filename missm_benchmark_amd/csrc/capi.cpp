@@ -16,7 +16,7 @@ void missm_set_error(const char* fmt, ...) {
 
 extern "C" const char* missm_last_error(void) { return g_err; }
 
-extern "C" int missm_abi_version(void) { return 10; }
+extern "C" int missm_abi_version(void) { return 11; }
 
 extern "C" int missm_device_count(void) {
   int n = 0;

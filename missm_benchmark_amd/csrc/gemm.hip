@@ -44,6 +44,8 @@ struct GemmArgs {
   unsigned long long* dbg;  // diagnostic builds only: per-workgroup {start, loop start, loop end, end, hw id} stamps (100 MHz clock)
   int group_m;              // tile order: groups of group_m tile rows are swept column by column (L2 locality)
   float* colsum_a;          // TA only: colsum_a[m] += sum_k A[k][m] (bias gradient riding in the dW GEMM as a ones-column)
+  int desync_phases, desync_step;   // experiment (MISSM_GEMM_DESYNC=<phases>,<ticks of 10 ns>): staggered first tiles of the persistent grid
+  unsigned* sched;          // persistent 8-phase NT grid: eight per-XCD tile-queue counters (device, zero between launches); null: static order
   // Grouped launch (8-phase kernels only): `ngroups` problems of ONE shape - the same linear of several shape-identical towers -
   // share a grid, so that B x 197-row towers fill the chip like one long tower does.  NT: tile rows [gi * group_tiles_m, ...)
   // belong to group gi; TN: workgroups [gi * tiles * splitk, ...).  A group's pointers replace the ones above.
@@ -887,7 +889,7 @@ extern "C" void missm_gemm_set_debug_buffer(void* p) { missm_gemm_debug_buffer =
 // Split-K workspaces: one per stream (launches on a stream are ordered, so consecutive split-K GEMMs may share one; GEMMs on
 // different streams run concurrently and must not).  Grown on demand - growth synchronises that stream once, during warm-up.
 namespace {
-struct SplitKWs { float* ws = nullptr; size_t bytes = 0; };
+struct SplitKWs { float* ws = nullptr; size_t bytes = 0; unsigned* sched = nullptr; };
 std::mutex g_ws_mu;
 std::unordered_map<void*, SplitKWs> g_ws;
 
@@ -905,12 +907,25 @@ int splitk_workspace(void* stream, size_t bytes, float** ws) {
   *ws = w.ws;
   return 0;
 }
+
+// the tile-queue counters of the dynamically scheduled persistent grid: one zero-filled 64-byte block per stream (launches on one
+// stream are ordered; every launch leaves its counters at zero)
+int tile_queue_counters(void* stream, unsigned** sched) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  SplitKWs& w = g_ws[stream];
+  if (!w.sched) {
+    if (hipMalloc(reinterpret_cast<void**>(&w.sched), 64) != hipSuccess) { w.sched = nullptr; return 1; }
+    if (hipMemset(w.sched, 0, 64) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { (void)hipFree(w.sched); w.sched = nullptr; return 1; }
+  }
+  *sched = w.sched;
+  return 0;
+}
 }  // namespace
 
 extern "C" void missm_gemm_release_workspaces(void) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   (void)hipDeviceSynchronize();
-  for (auto& kv : g_ws) if (kv.second.ws) (void)hipFree(kv.second.ws);
+  for (auto& kv : g_ws) { if (kv.second.ws) (void)hipFree(kv.second.ws); if (kv.second.sched) (void)hipFree(kv.second.sched); }
   g_ws.clear();
 }
 
@@ -948,7 +963,7 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
   g.A = A; g.B = B; g.C = C; g.M = M; g.N = N; g.K = K; g.lda = lda; g.ldb = ldb; g.ldc = ldc; g.alpha = alpha;
   g.bias = bias; g.resid = resid; g.aux_in = aux_in; g.aux_out = aux_out; g.ldaux = ldaux; g.act = act;
   g.out_f32 = out_f32; g.accumulate = accumulate; g.colsum_a = colsum_a;
-  g.ngroups = ngroups > 1 ? ngroups : 1; g.group_tiles_m = 0; g.tn_order = 0;
+  g.ngroups = ngroups > 1 ? ngroups : 1; g.group_tiles_m = 0; g.tn_order = 0; g.sched = nullptr; g.desync_phases = 0; g.desync_step = 0;
   if (ngroups > 1) {
     MISSM_CHECK_ARG(ngroups <= MISSM_MAX_GROUPS && groups, "gemm: too many groups");
     for (int i = 0; i < ngroups; ++i) g.grp[i] = groups[i];
@@ -1092,8 +1107,21 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
       }
       attr4 = true;
     }
+    // MISSM_GEMM_PERSIST4W=1: 512 resident workgroups draw their tiles from the per-XCD queues (gemm4w.h).  Parity-green and
+    // measured SLOWER than one workgroup per tile (QKV 182 vs 174 us, fc1 + QuickGELU 311 vs 301, same box): with the next tile's
+    // twenty requests per wave queued in front of them the epilogue's sixteen stores take 6.5 instead of 4.5 us to issue, which is
+    // more than the relaunch gap that the resident grid removes.  Default 0.
+    static const int persist4w = getenv("MISSM_GEMM_PERSIST4W") ? atoi(getenv("MISSM_GEMM_PERSIST4W")) : 0;
+    int nwg4 = g.tiles_m * g.tiles_n;
+    if (persist4w && nwg4 > 512) {
+      if (tile_queue_counters(stream, &g.sched)) {
+        missm_set_error("gemm: cannot allocate the tile-queue counters");
+        return MISSM_ERR_LAUNCH;
+      }
+      nwg4 = 512;
+    }
     log_shape(M);
-    hipLaunchKernelGGL(gemm4w_kernel, dim3(g.tiles_m * g.tiles_n), dim3(256), 80 * 1024, s, g);
+    hipLaunchKernelGGL(gemm4w_kernel, dim3(nwg4), dim3(256), 80 * 1024, s, g);
     return missm_check_launch("gemm4w");
   }
   dim3 grid(tiles * splitk), block(GEMM_THREADS);
@@ -1135,16 +1163,20 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
         auto k8 = use8p == 2 ? gemm8p_kernel<false> : gemm8p_kernel<true>;
         static bool attr8[2] = {false, false};
         if (!attr8[use8p == 2]) {
-          if (hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) != hipSuccess) {
+          if (hipFuncSetAttribute(reinterpret_cast<const void*>(k8), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024 + 16) != hipSuccess) {
             missm_set_error("gemm: cannot raise dynamic LDS to 128 KiB");
             return MISSM_ERR_LAUNCH;
           }
           attr8[use8p == 2] = true;
         }
-        // MISSM_GEMM_PERSIST=1: one workgroup per CU walks the tiles and requests the next tile's first half tiles before its
-        // epilogue.  Measured on the video shapes (same box, random data): +3 % on QKV / out-proj, -3 % on fc1 / its backward,
-        // 0 at 4096^3 - the hardware already starts the next workgroup under the previous one's draining stores.  Default off.
-        static const int persist = getenv("MISSM_GEMM_PERSIST") ? atoi(getenv("MISSM_GEMM_PERSIST")) : 0;
+        // MISSM_GEMM_PERSIST: 0 one workgroup per tile; 1 one workgroup per CU walks the tiles b, b + 256, ... and requests the next
+        // tile's first half tiles before its epilogue; 2 (default, round 3) the same grid DRAWS its tiles from per-XCD queues.
+        // Round 2 measured 1 against 0 at +-3 % and left it off: its tile-top wait (vmcnt(6)) sat behind every store of the epilogue.
+        // With the epilogue's operations counted into that wait and the dynamic order (in-kernel stamps, tools/gemm_timeline2.py:
+        // the relaunch gap of 2.4 - 4.8 us per tile becomes 0.9 us, a slow epilogue costs its CU a tile instead of holding the
+        // launch): QKV 174 - 181 -> 167 - 169 us, fc1 (no activation) 242 -> 228 - 235, four-tower QKV 93 -> 88, dX of fc2 167 -> 154,
+        // everything else within +-2 %; the two-stream step 67.24 / 67.03 -> 66.35 / 66.54 ms (alternating runs on one box).
+        static const int persist = getenv("MISSM_GEMM_PERSIST") ? atoi(getenv("MISSM_GEMM_PERSIST")) : 2;
         static int ncu = 0;
         if (ncu == 0) {
           int dev = 0; hipDeviceProp_t prop;
@@ -1152,8 +1184,17 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
           ncu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
         }
         const int nwg = persist ? (tmb * tn2 < ncu ? tmb * tn2 : ncu) : tmb * tn2;
+        if (persist == 2 && tmb * tn2 > ncu && ncu % 8 == 0 && tile_queue_counters(stream, &g.sched)) {
+          missm_set_error("gemm: cannot allocate the tile-queue counters");
+          return MISSM_ERR_LAUNCH;
+        }
+        static const char* desync_env = getenv("MISSM_GEMM_DESYNC");
+        if (desync_env && g.sched) {
+          int ph = 0, st = 0;
+          if (sscanf(desync_env, "%d,%d", &ph, &st) == 2) { g.desync_phases = ph; g.desync_step = st; }
+        }
         log_shape(g.M);
-        hipLaunchKernelGGL(k8, dim3(nwg), dim3(512), 128 * 1024, s, g);
+        hipLaunchKernelGGL(k8, dim3(nwg), dim3(512), 128 * 1024 + 16, s, g);
         return missm_check_launch("gemm8p");
       }
       if (ngroups > 1) return MISSM_GROUPED_UNAVAILABLE;

@@ -55,6 +55,45 @@ template <int B, int E, typename F> __device__ __forceinline__ void static_for(F
   }
 }
 
+// tile `logical` of the launch: its group's operand pointers (grouped launch), its origin and its buffer descriptors
+__device__ __forceinline__ void gemm4w_tile(const GemmArgs& gall, int logical, GemmArgs& g, Gemm4wSrc& src, int& m0, int& n0) {
+  int tm, tn;
+  tile_of(logical, gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
+  if (gall.ngroups > 1) {
+    const int gi = tm / gall.group_tiles_m;
+    tm -= gi * gall.group_tiles_m;
+    select_group(g, gall, gi);
+  }
+  m0 = tm * 256; n0 = tn * 128;
+  const bf16* A = static_cast<const bf16*>(g.A);
+  const bf16* B = static_cast<const bf16*>(g.B);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int ra = g.M - (m0 + 128 * h);
+    const unsigned na = ra <= 0 ? 0u : (unsigned)min(ra, 128) * (unsigned)g.lda * 2u;
+    src.a[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (size_t)(m0 + 128 * h) * g.lda), 0, na, 0x00020000);
+  }
+  const int rb = g.N - n0;
+  const unsigned nb = rb <= 0 ? 0u : (unsigned)min(rb, 128) * (unsigned)g.ldb * 2u;
+  src.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B + (size_t)n0 * g.ldb), 0, nb, 0x00020000);
+  src.none = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, 0, 0x00020000);
+}
+
+// half tiles s = 0 .. 4 of a tile (B0 A0_0 A1_0 | B1 A0_1) into slots 0 .. 4
+__device__ __forceinline__ void gemm4w_prologue(char* lds, const Gemm4wSrc& src, int wave, int nt) {
+  stage4w<0>(lds, 0, src, wave, 0, true);
+  stage4w<1>(lds, 1, src, wave, 0, true);
+  stage4w<2>(lds, 2, src, wave, 0, true);
+  stage4w<0>(lds, 3, src, wave, 128, nt > 1);
+  stage4w<1>(lds, 4, src, wave, 128, nt > 1);
+}
+
+// PERSISTENT form (gall.sched, round 3): 512 workgroups (two per CU) stay resident and draw their tiles from the per-XCD queues of
+// gemm8p.h.  In-kernel stamps of the one-tile-per-workgroup form showed why this kernel only tied with the 8-phase one on the
+// K = 768 video shapes although its two workgroups per CU hide each other's epilogue: a tile slot stood empty for 3.5 - 5 us between
+// two workgroups (a workgroup ends only when its stores have drained - 34 GB/s per CU - and its successor starts with a cold
+// prologue): 3546 QKV tiles x 17.5 us / 512 slots = 121 us of work in a 157 us launch.  Here the next tile's first five half tiles are
+// requested before the epilogue and the epilogue's stores stay in flight across the next tile's first counted wait.
 __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 5 slots x 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -64,31 +103,17 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
   const int ntiles = gall.tiles_m * gall.tiles_n;
   const int nt = gall.K >> 6;                // K tiles (host guarantees K % 64 == 0, K >= 128)
 
-  // ---- tile of this workgroup, its group's operands (grouped launch), buffer descriptors
+  // ---- tile of this workgroup (static: one tile; dynamic: queue entry blockIdx.x >> 3 of XCD queue blockIdx.x & 7 first, see gemm8p.h)
+  const bool dyn = gall.sched != nullptr;    // scalar
+  const int qx = blockIdx.x & 7;
+  const int q_cnt = (ntiles >> 3) + (qx < (ntiles & 7) ? 1 : 0);
+  const int q_start = xcd_remap(qx, ntiles);
+  const int q_wgs = ((int)gridDim.x >> 3) + (qx < ((int)gridDim.x & 7) ? 1 : 0);
+  int logical = xcd_remap((int)blockIdx.x, ntiles);
   GemmArgs g = gall;                         // (scalar fields only are ever read through this copy)
-  int tm, tn;
-  tile_of(xcd_remap((int)blockIdx.x, ntiles), gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
-  if (gall.ngroups > 1) {
-    const int gi = tm / gall.group_tiles_m;
-    tm -= gi * gall.group_tiles_m;
-    select_group(g, gall, gi);
-  }
-  const int m0 = tm * 256, n0 = tn * 128;
   Gemm4wSrc src;
-  {
-    const bf16* A = static_cast<const bf16*>(g.A);
-    const bf16* B = static_cast<const bf16*>(g.B);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int ra = g.M - (m0 + 128 * h);
-      const unsigned na = ra <= 0 ? 0u : (unsigned)min(ra, 128) * (unsigned)g.lda * 2u;
-      src.a[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (size_t)(m0 + 128 * h) * g.lda), 0, na, 0x00020000);
-    }
-    const int rb = g.N - n0;
-    const unsigned nb = rb <= 0 ? 0u : (unsigned)min(rb, 128) * (unsigned)g.ldb * 2u;
-    src.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B + (size_t)n0 * g.ldb), 0, nb, 0x00020000);
-    src.none = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, 0, 0x00020000);
-  }
+  int m0, n0;
+  gemm4w_tile(gall, logical, g, src, m0, n0);
   // ---- global -> LDS addressing.  LDS row r of a half tile holds 128 bytes of k, chunk c stored at c ^ (r & 7).
   //  A half ha : LDS row r <-> C row    m0 + 128 ha + r                         (wave wr reads rows 64 wr + 16 i + li)
   //  B         : LDS row r = 64 hb + r' <-> C column n0 + 64 (r' >> 5) + 4 (r' & 15) + 2 hb + ((r' >> 4) & 1)
@@ -102,14 +127,7 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
     const int col = 64 * (rp >> 5) + 4 * (rp & 15) + 2 * hb + ((rp >> 4) & 1);
     src.vb[q] = (unsigned)col * (unsigned)gall.ldb * 2u + (unsigned)c * 16u;
   }
-  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);   // (older than every half-tile request)
-
-  // ---- prologue: half tiles s = 0 .. 4  (B0 A0_0 A1_0 | B1 A0_1)
-  stage4w<0>(lds, 0, src, wave, 0, true);
-  stage4w<1>(lds, 1, src, wave, 0, true);
-  stage4w<2>(lds, 2, src, wave, 0, true);
-  stage4w<0>(lds, 3, src, wave, 128, nt > 1);
-  stage4w<1>(lds, 4, src, wave, 128, nt > 1);
+  gemm4w_prologue(lds, src, wave, nt);
 
   // ---- fragment read addresses (bytes): row * 128 + ((4 ks + lg) ^ (row & 7)) * 16; + slot base and 16-row-tile immediates
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -121,8 +139,13 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
     boff[ks] = lds0 + (unsigned)(wc * 32 + li) * 128u + sw;
   }
 
+  int epi_ops = 0;                           // vector-memory operations of the previous tile's epilogue (0: first tile / guarded path)
+  for (;;) {                                 // ---- one output tile per iteration
   unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;  // diagnostic runs only (tools/gemm_timeline.py)
   if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
+  unsigned drawn = 0;
+  if (dyn && tid == 0) drawn = __hip_atomic_fetch_add(gall.sched + qx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
   f32x4 acc[2][2][4][2];                     // [A half][B half][16-row tile][16-column tile]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -135,7 +158,13 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
 
   // (starting the workgroup in the odd hardware wave slot half a phase late - the two workgroups of a CU that start together
   //  might run phase-locked - was measured: no effect at 4096^3, +2 % at K = 2304 / 3072, -5..7 % at K = 768; not kept)
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // B0, A0_0, A1_0 have landed (this wave's pieces) ...
+  // B0, A0_0, A1_0 have landed (this wave's pieces).  Issue order: [5 half tiles = 20 requests | previous epilogue (epi_ops) | draw,
+  // bias]: they are complete once at most the youngest 8 + epi_ops operations are pending (the counter holds 6 bits).
+  if (epi_ops == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  else if (epi_ops == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
+  else if (epi_ops == 48) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
+  else if (epi_ops == 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                // ... everybody's
   if (g.dbg) t_loop = __builtin_amdgcn_s_memrealtime();
 
@@ -260,8 +289,35 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
 #undef MISSM_4W_FENCE_A
 #undef MISSM_4W_FENCE_AB
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
+  // every fragment read of this tile is complete and everybody is past the last barrier: all five slots are free.  The drawn queue
+  // entry travels through the first word of the (idle) ring - there is no LDS byte to spare at two workgroups per CU -, a second
+  // barrier keeps the next tile's requests behind everybody's read of it.
+  bool more = false;                         // wave-uniform
+  int nlogical = 0;
+  if (dyn) {
+    // (the word lies in wave 0's piece of slot 0: its last - dropped, zero-filling - requests must have landed before it is written)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(lds) = drawn;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned d = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(lds));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int k = q_wgs + (int)d;
+    more = k < q_cnt;
+    nlogical = q_start + k;
+    if ((int)d == q_cnt - 1 && tid == 0) __hip_atomic_store(gall.sched + qx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (more) {
+      GemmArgs gn = gall;
+      Gemm4wSrc srcn = src;
+      int m0n, n0n;
+      gemm4w_tile(gall, nlogical, gn, srcn, m0n, n0n);
+      gemm4w_prologue(lds, srcn, wave, nt);
+    }
+  }
 
-  if (!gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4)) {
+  epi_ops = gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4);
+  if (epi_ops < 0) {
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha) {
       typename AuxPre<bf16>::V upre[4][4];
@@ -276,10 +332,16 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
   }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
+    unsigned long long* d = g.dbg + (size_t)logical * 8;
     d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = t_issued;
     d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[5] = t_issued; d[6] = t_loop_end;
+    d[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15;    // XCC id
   }
+  if (!more) break;
+  logical = nlogical;
+  g = gall;
+  gemm4w_tile(gall, logical, g, src, m0, n0);
+  }                                          // ---- next tile
 }
 
 }  // namespace missm

@@ -44,10 +44,9 @@ __device__ __forceinline__ void stage_half(char* lds, const Gemm8pSrc& s, int wa
 }
 
 // tile `bid` of the launch: its group's operand pointers (grouped launch), its origin and its buffer descriptors
-__device__ __forceinline__ void gemm8p_tile(const GemmArgs& gall, int bid, GemmArgs& g, Gemm8pSrc& src, int& m0, int& n0) {
-  const int ntiles = gall.tiles_m * gall.tiles_n;
+__device__ __forceinline__ void gemm8p_tile(const GemmArgs& gall, int logical, GemmArgs& g, Gemm8pSrc& src, int& m0, int& n0) {
   int tm, tn;
-  tile_of(xcd_remap(bid, ntiles), gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
+  tile_of(logical, gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
   if (gall.ngroups > 1) {                    // grouped launch: this tile row's group supplies the operands
     const int gi = tm / gall.group_tiles_m;
     tm -= gi * gall.group_tiles_m;
@@ -104,7 +103,28 @@ struct Epi8p {
   __amdgpu_buffer_rsrc_t c, aux, res;
   unsigned vc, vaux;           // per-lane byte offsets (C / residual share one, the bf16 aux matrix has its own pitch)
   unsigned pitch_c, pitch_aux; // row pitch in bytes
+  unsigned wc, waux;           // per-lane byte offsets of the WIDE bf16 stores (below)
+  bool odd;                    // lane & 1
 };
+
+// WIDE bf16 stores.  A lane owns rows 4 lg + r (r = 0..3) x 4 consecutive columns of a 16-row tile: four 8-byte stores, and the
+// epilogue of a K = 768 tile was bound by their ISSUE, not by bandwidth (in-kernel stamps, round 3: 3.6 us for the 128 KiB of a QKV
+// tile, 7.7 us for the 256 KiB of an fc1 tile = 34 GB/s per CU, unchanged when the CUs' epilogues were moved out of phase).  Lane
+// pairs (li, li ^ 1) therefore trade halves through DPP: the even lane ends up with rows r = 0, 1 x 8 columns, the odd lane with
+// rows r = 2, 3 x 8 columns - two 16-byte stores per lane instead of four 8-byte ones, every wave instruction still writing whole
+// 128-byte lines (eight of them).
+__device__ __forceinline__ unsigned dpp_swap1(unsigned x) { return (unsigned)__builtin_amdgcn_mov_dpp((int)x, 0xB1, 0xf, 0xf, true); }
+template <int AUXBITS>
+__device__ __forceinline__ void store_wide_bf16(__amdgpu_buffer_rsrc_t rsrc, unsigned voff, unsigned pitch, unsigned soff, bool odd,
+                                                const u32x2 (&P)[4]) {
+  const u32x2 s0 = odd ? P[0] : P[2], s1 = odd ? P[1] : P[3];     // what the partner needs
+  const u32x2 k0 = odd ? P[2] : P[0], k1 = odd ? P[3] : P[1];     // what stays
+  const u32x2 r0 = {dpp_swap1(s0[0]), dpp_swap1(s0[1])}, r1 = {dpp_swap1(s1[0]), dpp_swap1(s1[1])};
+  const u32x4 w0 = odd ? u32x4{r0[0], r0[1], k0[0], k0[1]} : u32x4{k0[0], k0[1], r0[0], r0[1]};
+  const u32x4 w1 = odd ? u32x4{r1[0], r1[1], k1[0], k1[1]} : u32x4{k1[0], k1[1], r1[0], r1[1]};
+  __builtin_amdgcn_raw_buffer_store_b128(w0, rsrc, voff, soff, AUXBITS);
+  __builtin_amdgcn_raw_buffer_store_b128(w1, rsrc, voff + pitch, soff, AUXBITS);
+}
 
 __device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) {
   bf16x4 r = {(bf16)v[0], (bf16)v[1], (bf16)v[2], (bf16)v[3]};
@@ -141,6 +161,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
       }
     };
     request(0, u[0]);
+    u32x2 pk[4];
 #pragma unroll
     for (int ch = 0; ch < 4; ++ch) {
       if (ch + 1 < 4) request(ch + 1, u[(ch + 1) & 1]);
@@ -151,7 +172,8 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
         const f32x4 uu = unpack_bf16x4(u[ch & 1][k]);
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] *= quick_gelu_grad(uu[j]);
-        __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), MISSM_EPI_AUX);
+        pk[r] = pack_bf16x4(v);
+        if (r == 3) store_wide_bf16<MISSM_EPI_AUX>(e.c, e.wc, e.pitch_c, MISSM_SC(ha, i), e.odd, pk);
       }
     }
   } else if constexpr (MODE == 3) {
@@ -188,17 +210,23 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha)
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int i = 0; i < 4; ++i) {
+        u32x2 pu[4], pa[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           f32x4 v = MISSM_VAL(ha, i, r);
           if constexpr (MODE == 1) {
-            if (has_aux) __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.aux, var[r], MISSM_SA(ha, i), MISSM_EPI_AUX);
+            pu[r] = pack_bf16x4(v);
 #pragma unroll
             for (int j = 0; j < 4; ++j) v[j] = quick_gelu(v[j]);
           }
-          __builtin_amdgcn_raw_buffer_store_b64(pack_bf16x4(v), e.c, vcr[r], MISSM_SC(ha, i), MISSM_EPI_AUX);
+          pa[r] = pack_bf16x4(v);
         }
+        if constexpr (MODE == 1) {
+          if (has_aux) store_wide_bf16<MISSM_EPI_AUX>(e.aux, e.waux, e.pitch_aux, MISSM_SA(ha, i), e.odd, pu);
+        }
+        store_wide_bf16<MISSM_EPI_AUX>(e.c, e.wc, e.pitch_c, MISSM_SC(ha, i), e.odd, pa);
+      }
   }
 #undef MISSM_VAL
 #undef MISSM_SC
@@ -206,9 +234,10 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
 }
 
 // The wave's 128 x 64 outputs (rows mwb + 128 ha + 16 i + 4 lg + r, columns nw + 4 li ..+3) through the branch-free epilogue;
-// false if the case is not covered (the caller takes the guarded epilogue of gemm.hip): buffer offsets are 32-bit, so matrices of
-// 4 GiB and more, ragged column blocks, accumulate and the rare activations stay there.
-__device__ __forceinline__ bool gemm8p_store_tile(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], int mwb, int nw, int lane,
+// returns the number of vector-memory operations it issued (16 .. 64: the persistent grid counts them into the next tile's first
+// vmcnt wait), or -1 if the case is not covered (the caller takes the guarded epilogue of gemm.hip): buffer offsets are 32-bit, so
+// matrices of 4 GiB and more, ragged column blocks, accumulate and the rare activations stay there.
+__device__ __forceinline__ int gemm8p_store_tile(const GemmArgs& g, const f32x4 (&acc)[2][2][4][2], int mwb, int nw, int lane,
                                                   f32x4 bias4) {
   const int li = lane & 15, lg = lane >> 4;
   const int esz = g.out_f32 ? 4 : 2;
@@ -218,7 +247,7 @@ __device__ __forceinline__ bool gemm8p_store_tile(const GemmArgs& g, const f32x4
   const bool has_aux = auxp != nullptr;
   const bool fast = mode >= 0 && g.vec_ok && !g.accumulate && nw + 64 <= g.N && (mode != 2 || has_aux) && (mode == 3 || !g.resid) &&
                     (size_t)g.M * g.ldc * esz < (size_t(1) << 32) && (size_t)g.M * g.ldaux * 2 < (size_t(1) << 32);
-  if (!fast) return false;
+  if (!fast) return -1;
   Epi8p e;
   e.pitch_c = (unsigned)g.ldc * esz; e.pitch_aux = (unsigned)g.ldaux * 2u;
   const unsigned rows = (unsigned)min(max(g.M - mwb, 0), 192);
@@ -232,11 +261,14 @@ __device__ __forceinline__ bool gemm8p_store_tile(const GemmArgs& g, const f32x4
                   : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
   e.vc = (unsigned)(lg * 4) * e.pitch_c + (unsigned)(nw + li * 4) * esz;
   e.vaux = (unsigned)(lg * 4) * e.pitch_aux + (unsigned)(nw + li * 4) * 2u;
-  if (mode == 0) gemm8p_epilogue<0>(e, false, false, g.alpha, bias4, acc);
-  else if (mode == 1) gemm8p_epilogue<1>(e, has_aux, false, g.alpha, bias4, acc);
-  else if (mode == 2) gemm8p_epilogue<2>(e, true, false, g.alpha, bias4, acc);
-  else gemm8p_epilogue<3>(e, false, g.resid != nullptr, g.alpha, bias4, acc);
-  return true;
+  e.odd = (li & 1) != 0;
+  e.wc = (unsigned)(lg * 4 + 2 * (li & 1)) * e.pitch_c + (unsigned)(nw + (li >> 1) * 8) * 2u;      // (bf16 C only)
+  e.waux = (unsigned)(lg * 4 + 2 * (li & 1)) * e.pitch_aux + (unsigned)(nw + (li >> 1) * 8) * 2u;
+  if (mode == 0) { gemm8p_epilogue<0>(e, false, false, g.alpha, bias4, acc); return 16; }
+  if (mode == 1) { gemm8p_epilogue<1>(e, has_aux, false, g.alpha, bias4, acc); return has_aux ? 32 : 16; }
+  if (mode == 2) { gemm8p_epilogue<2>(e, true, false, g.alpha, bias4, acc); return 48; }
+  gemm8p_epilogue<3>(e, false, g.resid != nullptr, g.alpha, bias4, acc);
+  return g.resid != nullptr ? 64 : 32;
 }
 
 // STAGGER: waves 4-7 run one barrier behind waves 0-3.
@@ -258,11 +290,25 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   //  A half ha : LDS row r <-> C row   m0 + 128 ha + r                       (wave wr reads rows 64 wr + 16 i + li)
   //  B half hb : LDS row r <-> C column n0 + 64 (r >> 5) + 4 (r & 15) + 2 hb + ((r >> 4) & 1)
   //              (wave wc reads rows 32 wc + 16 j + li: with both halves a lane owns 4 CONSECUTIVE columns 64 wc + 4 li + 0..3)
-  int bid = blockIdx.x;
+  // Tile order.  Static: workgroup b walks the hardware-order ids b, b + gridDim.x, ... (logical id = xcd_remap(id): workgroups that
+  // share b & 7 share an XCD under round-robin placement and get one contiguous range of logical tiles - L2 locality, speed only).
+  // DYNAMIC (gall.sched, persistent grids only): that XCD range is a QUEUE - the first tile of workgroup b is entry b >> 3, every
+  // further one is drawn with one returning atomic on the queue's counter at the TOP of the tile before (a microsecond of latency
+  // under a 16 us main loop).  A slow tile (epilogue stores colliding: p90 8 us against a median of 3.7) then costs its CU one
+  // tile less instead of making the launch wait for it.  Every workgroup ends on exactly one failing draw, so queue x sees
+  // cnt_x draws in all: the draw that returns cnt_x - 1 is the last one and puts the counter back to zero for the next launch.
+  const bool dyn = gall.sched != nullptr;    // scalar
+  const int qx = blockIdx.x & 7;
+  const int q_cnt = (ntiles >> 3) + (qx < (ntiles & 7) ? 1 : 0);             // tiles in this workgroup's queue
+  const int q_start = xcd_remap(qx, ntiles);                                 // its first logical id
+  const int q_wgs = ((int)gridDim.x >> 3) + (qx < ((int)gridDim.x & 7) ? 1 : 0);   // workgroups that serve it (each starts on a static entry)
+  int bid = blockIdx.x;                      // hardware-order id (static order; also the diagnostic stamp slot)
+  int logical = xcd_remap(bid, ntiles);
+  if (dyn) bid = logical;
   GemmArgs g = gall;                         // (scalar fields only are ever read through this copy)
   Gemm8pSrc src;
   int m0, n0;
-  gemm8p_tile(gall, bid, g, src, m0, n0);
+  gemm8p_tile(gall, logical, g, src, m0, n0);
 #pragma unroll
   for (int q = 0; q < 2; ++q) {
     const int r = 16 * wave + 8 * q + (lane >> 3);           // LDS row inside the half tile
@@ -286,10 +332,18 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   // (measured and removed: starting the first round of workgroups (b / 8) % 8 x 2.5 us apart, so that the CUs' epilogues do
   //  not all hit HBM in the same phase: -1..-20 % on every video shape)
   gemm8p_prologue(lds, src, wave, nt);
+  if (gall.desync_phases > 1) {               // experiment: start the workgroups of an XCD in `desync_phases` groups, desync_step ticks apart
+    const unsigned long long t_in = __builtin_amdgcn_s_memrealtime();
+    const unsigned long long wait = (unsigned long long)(((int)blockIdx.x >> 3) % gall.desync_phases) * (unsigned long long)gall.desync_step;
+    while (__builtin_amdgcn_s_memrealtime() - t_in < wait) __builtin_amdgcn_s_sleep(4);
+  }
+  int epi_ops = 0;                           // vector-memory operations of the previous tile's epilogue (0: first tile / guarded path)
 
   for (;;) {                                 // ---- one output tile per iteration
   unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;       // diagnostic runs only (tools/gemm_timeline.py)
   if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
+  unsigned drawn = 0;
+  if (dyn && tid == 0) drawn = __hip_atomic_fetch_add(gall.sched + qx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
   f32x4 acc[2][2][4][2];                     // [A half][B half][16-row tile][16-column tile]
 #pragma unroll
@@ -300,9 +354,16 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
       for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-  // K tile 0 has landed (this wave's pieces): of the requests [7 half tiles | previous epilogue | bias] at most the youngest 6
-  // are pending - on the first tile that leaves K tile 1's three half tiles in flight, later everything older than the bias
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  // K tile 0 has landed (this wave's pieces).  Requests in issue order: [7 half tiles | the previous tile's epilogue (epi_ops loads /
+  // stores) | bias (0-4 loads)]: K tile 0 is complete once at most the youngest 6 + epi_ops are pending - K tile 1's three half
+  // tiles AND the epilogue's stores stay in flight (round 2 waited vmcnt(6) here, i.e. for every store of the epilogue to be
+  // acknowledged: that wait was the persistent grid's whole loss against a relaunch).  The counter holds 6 bits: 63 is still a
+  // lower bound on what is younger than K tile 0 when epi_ops = 64.
+  if (epi_ops == 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
+  else if (epi_ops == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
+  else if (epi_ops == 48) asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
+  else if (epi_ops == 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
   __builtin_amdgcn_s_barrier();                                // ... everybody's
   if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();        // waves 4-7 fall one barrier behind (re-joined after the loop)
   if (g.dbg) t_loop = __builtin_amdgcn_s_memrealtime();
@@ -391,23 +452,40 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
 #undef MISSM_8P_READ_A
 #undef MISSM_8P_READ_B
 #undef MISSM_8P_FENCE_ALL
+  if (dyn) {                                 // the draw went out a whole main loop ago: hand it to the other waves through LDS
+    if (tid == 0) *reinterpret_cast<volatile unsigned*>(lds + 131072) = drawn;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (!STAGGER) __builtin_amdgcn_s_barrier();
+  }
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();        // waves 0-3 wait for the lagging group
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
   // every fragment read of this tile is complete (phase 3 reads nothing and everybody is past its last barrier): all slots are
   // free.  Request the NEXT tile's first half tiles now; the (dropped) requests past the last K tile are older and harmless.
-  const int nbid = bid + (int)gridDim.x;
-  const bool more = nbid < ntiles;           // wave-uniform
+  int nbid = bid + (int)gridDim.x, nlogical;
+  bool more;                                 // wave-uniform
+  if (dyn) {
+    const unsigned d = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(lds + 131072));
+    const int k = q_wgs + (int)d;            // queue entry (entries 0 .. q_wgs - 1 were the static first tiles)
+    more = k < q_cnt;
+    nlogical = q_start + k;
+    nbid = nlogical;                         // (stamp slot of the diagnostic runs: any unique id)
+    if ((int)d == q_cnt - 1 && tid == 0) __hip_atomic_store(gall.sched + qx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  } else {
+    more = nbid < ntiles;
+    nlogical = xcd_remap(nbid, ntiles);
+  }
   if (more) {                                // (descriptors are rebuilt after the epilogue rather than kept: scalar registers)
     GemmArgs gn = gall;
     Gemm8pSrc srcn = src;
     int m0n, n0n;
-    gemm8p_tile(gall, nbid, gn, srcn, m0n, n0n);
+    gemm8p_tile(gall, nlogical, gn, srcn, m0n, n0n);
     gemm8p_prologue(lds, srcn, wave, nt);
   }
 
   // ---- epilogue: two 64 x 64 blocks per wave (A half 0 / 1), a lane owns rows 4 lg + r of each 16-row tile and the four
   // consecutive columns 64 wc + 4 li + {0, 1 (B half 0), 2, 3 (B half 1)}: the same register picture as gemm_kernel's.
-  if (!gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4)) {
+  epi_ops = gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4);
+  if (epi_ops < 0) {
     // (guarded epilogue of gemm.hip, dependent loads issued at their use: matrices of 4 GiB and more, rare activations)
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha) {
@@ -426,11 +504,12 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
     unsigned long long* d = g.dbg + (size_t)bid * 8;
     d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = t_issued;
     d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[5] = t_issued; d[6] = t_loop_end;
+    d[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15;    // XCC id
   }
   if (!more) break;
-  bid = nbid;
+  bid = nbid; logical = nlogical;
   g = gall;
-  gemm8p_tile(gall, bid, g, src, m0, n0);
+  gemm8p_tile(gall, logical, g, src, m0, n0);
   }                                          // ---- next tile
 }
 

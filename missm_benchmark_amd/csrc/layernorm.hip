@@ -130,12 +130,17 @@ struct LnBwdArgs {
   float* dgamma; float* dbeta;  // fp32 [cols], atomically accumulated (caller zeroes)
   int rows, cols;
   void* dx_cast;         // optional Tin copy of the updated dx rows (GEMM operand of the next backward block)
+  // optional group sums of the UPDATED dx rows: gsum[(row / gs_div) % gs_mod][col] += dx[row][col] (atomics; caller zeroes) - the
+  // temporal-embedding gradient of the video tower (rows of one frame are one run of gs_div = S rows, the frame's time index is its
+  // group), which used to be a separate column-sum pass over the 155 MB residual gradient.  Instantiated as GS: a wave then walks the
+  // rows of ONE frame (workgroup = 4 waves of one frame, `gridDim.x * 4 / (rows / gs_div)` waves per frame) and carries one sum.
+  float* gsum; int gs_div, gs_mod;
 };
 
 // FAST: cols == CH * 256, accumulate, dx_cast and no row gather - the residual-stream LayerNorms of every tower layer.  With the
 // column guards and the uniform branches gone the loop is straight-line code, so the compiler can COUNT the memory operations:
 // it waits for the prefetched row with vmcnt(#stores issued after it) instead of vmcnt(0) on the stores' write acknowledgements.
-template <typename Tin, int CH, bool FAST>
+template <typename Tin, int CH, bool FAST, bool GS = false>
 __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) {
   __shared__ float red[2][4][CH * 256];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -172,9 +177,17 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) 
     }
     nmean = a.mean[row]; nrstd = a.rstd[row];
   };
-  const int row0 = bx * 4 + wave, rstep = gx * 4;
-  if (row0 < a.rows) issue(row0);
-  for (int row = row0; row < a.rows; row += rstep) {
+  int row0 = bx * 4 + wave, rstep = gx * 4, rend = a.rows, grp = 0;
+  f32x4 asum[GS ? CH : 1];
+  if constexpr (GS) {
+    const int wpf = (gx * 4) / (a.rows / a.gs_div);           // waves per frame (host: an exact multiple of 4)
+    const int w = bx * 4 + wave, f = w / wpf;
+    row0 = f * a.gs_div + (w - f * wpf); rstep = wpf; rend = (f + 1) * a.gs_div; grp = f % a.gs_mod;
+#pragma unroll
+    for (int c = 0; c < CH; ++c) asum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  if (row0 < rend) issue(row0);
+  for (int row = row0; row < rend; row += rstep) {
     const size_t irow = (size_t)row * a.in_mul + ((!FAST && a.in_off) ? a.in_off[row] : 0);
     const float mean = nmean, rstd = nrstd;
     f32x4 xh[CH], g[CH], prev[CH];
@@ -201,7 +214,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) 
         xh[c] = f32x4{0.f, 0.f, 0.f, 0.f}; g[c] = f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
-    if (row + rstep < a.rows) issue(row + rstep);
+    if (row + rstep < rend) issue(row + rstep);
     s1 = wave_sum(s1) * inv;
     s2 = wave_sum(s2) * inv;
 #pragma unroll
@@ -214,6 +227,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) 
         o += prev[c];
         store4(dxr + col, o);
         if (FAST || a.dx_cast) store4(static_cast<Tin*>(a.dx_cast) + irow * a.cols + col, o);
+        if constexpr (GS) asum[c] += o;
       }
     }
   }
@@ -230,10 +244,21 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) 
     if (a.dgamma) atomicAdd(a.dgamma + col, sg);
     if (a.dbeta) atomicAdd(a.dbeta + col, sb);
   }
+  if constexpr (GS) {                        // the four waves of a workgroup walked one frame: one atomic per column
+    __syncthreads();
+#pragma unroll
+    for (int c = 0; c < CH; ++c) store4(&red[0][wave][(c * 64 + lane) * 4], asum[c]);
+    __syncthreads();
+    float* gs = a.gsum + (size_t)grp * a.cols;
+    for (int col = threadIdx.x; col < a.cols; col += 256)
+      atomicAdd(gs + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
+  }
 }
 
 template <typename Tin, int CH, bool FAST = false>
 __global__ __launch_bounds__(256) void ln_bwd_kernel(LnBwdArgs a) { ln_bwd_body<Tin, CH, FAST>(a, blockIdx.x, gridDim.x); }
+template <typename Tin, int CH, bool FAST = false>
+__global__ __launch_bounds__(256) void ln_bwd_gs_kernel(LnBwdArgs a) { ln_bwd_body<Tin, CH, FAST, true>(a, blockIdx.x, gridDim.x); }
 
 struct LnBwdGroups { const void* dy[LN_MAX_GROUPS]; const float* x[LN_MAX_GROUPS]; const float* mean[LN_MAX_GROUPS]; const float* rstd[LN_MAX_GROUPS];
                      const float* gamma[LN_MAX_GROUPS]; float* dx[LN_MAX_GROUPS]; float* dgamma[LN_MAX_GROUPS]; float* dbeta[LN_MAX_GROUPS];
@@ -290,12 +315,30 @@ extern "C" int missm_layernorm_fwd(const float* x, float* x_wb, const float* add
   return missm_check_launch("layernorm_fwd");
 }
 
-extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
-                                   const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate,
-                                   float* dgamma, float* dbeta, void* dx_cast, int rows, int cols, int dy_dtype, void* stream) {
+static int layernorm_bwd_core(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
+                              const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate,
+                              float* dgamma, float* dbeta, void* dx_cast, float* gsum, int gs_div, int gs_mod, int rows, int cols,
+                              int dy_dtype, void* stream) {
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd: cols must be a positive multiple of 4");
   LnBwdArgs a{dy, dy_div > 0 ? dy_div : 1, dy_scale, x, in_mul > 0 ? in_mul : 1, in_off, mean, rstd, gamma, dx, accumulate,
-              dgamma, dbeta, rows, cols, dx_cast};
+              dgamma, dbeta, rows, cols, dx_cast, gsum, gs_div, gs_mod};
+  if (gsum) {
+    MISSM_CHECK_ARG(gs_div > 0 && gs_mod > 0 && rows % gs_div == 0 && !in_off && a.in_mul == 1, "layernorm_bwd: group sums need rows = frames x gs_div, no row gather");
+    const int frames = rows / gs_div;
+    const int wpf = frames <= 1024 ? 8 : 4;        // waves per frame (video tower at B = 32: 256 frames x 8 = the 512-workgroup grid)
+    dim3 grid(frames * wpf / 4), block(256);
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    int rc = dispatch_ch<void>(cols, [&](auto ch) {
+      constexpr int CH = decltype(ch)::value;
+      const bool fast = cols == CH * 256 && accumulate && dx_cast;
+      if (dy_dtype == kBF16 && fast) hipLaunchKernelGGL((ln_bwd_gs_kernel<bf16, CH, true>), grid, block, 0, s, a);
+      else if (dy_dtype == kBF16) hipLaunchKernelGGL((ln_bwd_gs_kernel<bf16, CH>), grid, block, 0, s, a);
+      else hipLaunchKernelGGL((ln_bwd_gs_kernel<float, CH>), grid, block, 0, s, a);
+      return MISSM_OK;
+    });
+    if (rc != MISSM_OK) return rc;
+    return missm_check_launch("layernorm_bwd_groupsum");
+  }
   // grid cap: round 1's kernel (one row in flight per wave) wanted 768-1024 workgroups; with the rows software-pipelined two
   // workgroups per CU already keep the memory pipe full, and fewer blocks mean fewer dgamma / dbeta atomics and less pressure on
   // the second stream: inside the two-stream step 512 measures 463.5 samples/s against 460.4 at 768 and 462.9 at 384
@@ -314,6 +357,21 @@ extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, c
   });
   if (rc != MISSM_OK) return rc;
   return missm_check_launch("layernorm_bwd");
+}
+
+extern "C" int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float* x, int in_mul, const int* in_off,
+                                   const float* mean, const float* rstd, const float* gamma, float* dx, int accumulate,
+                                   float* dgamma, float* dbeta, void* dx_cast, int rows, int cols, int dy_dtype, void* stream) {
+  return layernorm_bwd_core(dy, dy_div, dy_scale, x, in_mul, in_off, mean, rstd, gamma, dx, accumulate, dgamma, dbeta, dx_cast, nullptr, 1, 1,
+                            rows, cols, dy_dtype, stream);
+}
+
+extern "C" int missm_layernorm_bwd_groupsum(const void* dy, float dy_scale, const float* x, const float* mean, const float* rstd,
+                                            const float* gamma, float* dx, int accumulate, float* dgamma, float* dbeta, void* dx_cast,
+                                            float* gsum, int gs_div, int gs_mod, int rows, int cols, int dy_dtype, void* stream) {
+  MISSM_CHECK_ARG(gsum != nullptr, "layernorm_bwd_groupsum: gsum is required");
+  return layernorm_bwd_core(dy, 1, dy_scale, x, 1, nullptr, mean, rstd, gamma, dx, accumulate, dgamma, dbeta, dx_cast, gsum, gs_div, gs_mod,
+                            rows, cols, dy_dtype, stream);
 }
 
 extern "C" int missm_layernorm_fwd_grouped(int ngroups, const float* const* x, const float* const* gamma, const float* const* beta, void* const* y,
@@ -342,7 +400,7 @@ extern "C" int missm_layernorm_bwd_grouped(int ngroups, const void* const* dy, c
                                            float* const* dbeta, void* const* dx_cast, int rows, int cols, int dy_dtype, void* stream) {
   MISSM_CHECK_ARG(ngroups >= 1 && ngroups <= LN_MAX_GROUPS && dy && x && mean && rstd && gamma && dx && dx_cast, "layernorm_bwd_grouped: 1..8 groups");
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd_grouped: cols must be a positive multiple of 4");
-  LnBwdArgs a{nullptr, 1, 1.0f, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, rows, cols, nullptr};
+  LnBwdArgs a{nullptr, 1, 1.0f, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, rows, cols, nullptr, nullptr, 1, 1};
   LnBwdGroups gs;
   for (int g = 0; g < ngroups; ++g) {
     gs.dy[g] = dy[g]; gs.x[g] = x[g]; gs.mean[g] = mean[g]; gs.rstd[g] = rstd[g]; gs.gamma[g] = gamma[g]; gs.dx[g] = dx[g];

@@ -191,9 +191,17 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, *, add=None, a
 
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, cols, *, accumulate=True, dy_div=1, dy_scale=1.0,
-                  in_mul=1, in_off=None, dx_cast=None):
+                  in_mul=1, in_off=None, dx_cast=None, gsum=None, gs_div=1, gs_mod=1):
+    """gsum (fp32 [gs_mod, cols], caller zeroes): gsum[(row // gs_div) % gs_mod] += the updated dx rows, in the same pass"""
     if dx_cast is not None and dx_cast.dtype != dy.dtype:
         raise _lib.MissmError("layernorm_bwd: dx_cast must have dy's dtype")
+    if gsum is not None:
+        if dy_div != 1 or in_mul != 1 or in_off is not None or gsum.dtype != torch.float32 or gsum.numel() < gs_mod * cols:
+            raise _lib.MissmError("layernorm_bwd: group sums need the plain row mapping and an fp32 [gs_mod, cols] output")
+        _lib.call("missm_layernorm_bwd_groupsum", dy.data_ptr(), float(dy_scale), x.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  gamma.data_ptr(), dx.data_ptr(), int(accumulate), _p(dgamma), _p(dbeta), _p(dx_cast), gsum.data_ptr(), gs_div, gs_mod,
+                  rows, cols, dt(dy), _s())
+        return dx
     _lib.call("missm_layernorm_bwd", dy.data_ptr(), dy_div, float(dy_scale), x.data_ptr(), in_mul, _p(in_off), mean.data_ptr(),
               rstd.data_ptr(), gamma.data_ptr(), dx.data_ptr(), int(accumulate), _p(dgamma), _p(dbeta), _p(dx_cast), rows, cols,
               dt(dy), _s())

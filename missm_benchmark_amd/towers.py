@@ -855,9 +855,11 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
             dxt = E(rows, d, device=dev, dtype=T)
             _linear_bwd_lanes(towers, dqkv, xt, W(f"{pfx}.tqkv", 1), [l.g_tqkv_w for l in L], [l.g_tqkv_b for l in L], rows, dx_outs=dxt, lora_sites=LS("tqkv"))
             for g in G:
-                ops.layernorm_bwd(dxt[g], hin[g], mt[g], rt[g], L[g].tln_w, dh[g], L[g].g_tln_w, L[g].g_tln_b, rows, d, accumulate=True, dx_cast=dh_T[g])
-                if Tf != 1 and L[g].g_temb is not None:
-                    ops.colsum(dh[g], L[g].g_temb, div=S, mod=Tf, R=rows)
+                # d temporal_embedding[t] = sum over (b, n) of the updated residual gradient: group sums riding in the LayerNorm backward
+                # (a separate column-sum pass over the 155 MB video gradient until round 3)
+                temb = L[g].g_temb if Tf != 1 else None
+                ops.layernorm_bwd(dxt[g], hin[g], mt[g], rt[g], L[g].tln_w, dh[g], L[g].g_tln_w, L[g].g_tln_b, rows, d, accumulate=True, dx_cast=dh_T[g],
+                                  gsum=temb, gs_div=S, gs_mod=Tf)
         for g in G:
             states[g].layers[i] = None
         if i % t0.bucket_layers == 0:

@@ -328,6 +328,40 @@ def test_layernorm_bwd_gather_multi_trip(ops, idt):
     assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4     # (4101-term fp32 sums through atomics)
 
 
+@pytest.mark.parametrize("idt", DTYPES)
+@pytest.mark.parametrize("B,T,S,d,cast", [(2, 8, 197, 768, True), (3, 4, 5, 768, True), (2, 3, 7, 64, False), (1, 8, 33, 256, True)])
+def test_layernorm_bwd_group_sums(ops, idt, B, T, S, d, cast):
+    """The temporal-embedding gradient riding in temporal_layer_norm1's backward (image/modeling_image.py:114-119):
+    gsum[t] += sum over (b, n) of the UPDATED residual gradient, every frame walked by the waves of whole workgroups - the straight-line
+    instantiation (768 columns, dx_cast) and the generic one, frames shorter than the waves per frame, a non-zero gsum to add to."""
+    rows = B * T * S
+    x, g = rnd(rows, d, seed=1), 1 + 0.1 * rnd(d, seed=2)
+    dy = q(rnd(rows, d, seed=4), idt)
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), torch.zeros(d, requires_grad=True)
+    F.layer_norm(xr, (d,), gr, br, 1e-5).backward(0.5 * dy)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    dx0 = rnd(rows, d, seed=5)
+    want = dx0 + xr.grad
+    gs0 = rnd(T + 1, d, seed=6)                      # row T must stay untouched
+    dx, gs = dev(dx0.clone()), dev(gs0.clone())
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    dxc = torch.empty(rows, d, device="cuda", dtype=idt) if cast else None
+    ops.layernorm_bwd(dev(dy, idt), dev(x), dev(mean), dev(rstd), dev(g), dx, dg, db, rows, d, accumulate=True, dy_scale=0.5, dx_cast=dxc,
+                      gsum=gs, gs_div=S, gs_mod=T)
+    assert rel(dx, want) < 2e-5
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    if cast:
+        assert rel(dxc, want) < TOL[idt]
+    ref = gs0.clone()
+    ref[:T] += want.view(B, T, S, d).sum((0, 2))
+    assert rel(gs[:T], ref[:T]) < 1e-4
+    assert torch.equal(gs[T].cpu(), gs0[T])
+    # the separate column-sum pass it replaces gives the same numbers
+    gs2 = dev(gs0.clone())
+    ops.colsum(dx, gs2, div=S, mod=T, R=rows)
+    assert rel(gs2[:T], gs[:T]) < 1e-4
+
+
 # ------------------------------------------------------------------ attention
 def attn_ref(qkv, nseq, L, H, hd, rowidx, causal, key_mask):
     """fp32 reference on gathered rows: returns out rows and a function giving d(qkv) for a cotangent"""
