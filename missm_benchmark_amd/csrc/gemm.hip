@@ -1107,20 +1107,25 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
       }
       attr4 = true;
     }
-    // MISSM_GEMM_PERSIST4W=1: 512 resident workgroups draw their tiles from the per-XCD queues (gemm4w.h).  Parity-green and
-    // measured SLOWER than one workgroup per tile (QKV 182 vs 174 us, fc1 + QuickGELU 311 vs 301, same box): with the next tile's
-    // twenty requests per wave queued in front of them the epilogue's sixteen stores take 6.5 instead of 4.5 us to issue, which is
-    // more than the relaunch gap that the resident grid removes.  Default 0.
-    static const int persist4w = getenv("MISSM_GEMM_PERSIST4W") ? atoi(getenv("MISSM_GEMM_PERSIST4W")) : 0;
-    int nwg4 = g.tiles_m * g.tiles_n;
-    if (persist4w && nwg4 > 512) {
-      if (tile_queue_counters(stream, &g.sched)) {
-        missm_set_error("gemm: cannot allocate the tile-queue counters");
-        return MISSM_ERR_LAUNCH;
-      }
-      nwg4 = 512;
-    }
+    // MISSM_GEMM_4WC=1: the resident, K-continuous form of this kernel (gemm4w.h: gemm4wc_kernel) where the grid has more than 512 tiles.
+    // (A first resident form that requested the next tile's five prologue half tiles in front of the epilogue and drew tiles from the
+    //  per-XCD queues was parity-green and SLOWER than one workgroup per tile - QKV 182 vs 174 us, fc1 + QuickGELU 311 vs 301, same box:
+    //  twenty requests per wave queued in front of the sixteen stores, which took 6.5 instead of 4.5 us to issue.  Removed.)
+    static const int cont4w = getenv("MISSM_GEMM_4WC") ? atoi(getenv("MISSM_GEMM_4WC")) : 0;
+    const int nwg4 = g.tiles_m * g.tiles_n;
     log_shape(M);
+    if (cont4w && nwg4 > 512 && K >= 192) {    // resident grid, K loop continuous across tiles (gemm4wc_kernel)
+      static bool attr4c = false;
+      if (!attr4c) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(gemm4wc_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) {
+          missm_set_error("gemm: cannot raise dynamic LDS to 80 KiB");
+          return MISSM_ERR_LAUNCH;
+        }
+        attr4c = true;
+      }
+      hipLaunchKernelGGL(gemm4wc_kernel, dim3(512), dim3(256), 80 * 1024, s, g);
+      return missm_check_launch("gemm4wc");
+    }
     hipLaunchKernelGGL(gemm4w_kernel, dim3(nwg4), dim3(256), 80 * 1024, s, g);
     return missm_check_launch("gemm4w");
   }

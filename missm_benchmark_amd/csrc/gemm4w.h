@@ -88,12 +88,6 @@ __device__ __forceinline__ void gemm4w_prologue(char* lds, const Gemm4wSrc& src,
   stage4w<1>(lds, 4, src, wave, 128, nt > 1);
 }
 
-// PERSISTENT form (gall.sched, round 3): 512 workgroups (two per CU) stay resident and draw their tiles from the per-XCD queues of
-// gemm8p.h.  In-kernel stamps of the one-tile-per-workgroup form showed why this kernel only tied with the 8-phase one on the
-// K = 768 video shapes although its two workgroups per CU hide each other's epilogue: a tile slot stood empty for 3.5 - 5 us between
-// two workgroups (a workgroup ends only when its stores have drained - 34 GB/s per CU - and its successor starts with a cold
-// prologue): 3546 QKV tiles x 17.5 us / 512 slots = 121 us of work in a 157 us launch.  Here the next tile's first five half tiles are
-// requested before the epilogue and the epilogue's stores stay in flight across the next tile's first counted wait.
 __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 5 slots x 16 KiB
   const int tid = threadIdx.x, lane = tid & 63;
@@ -103,17 +97,31 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
   const int ntiles = gall.tiles_m * gall.tiles_n;
   const int nt = gall.K >> 6;                // K tiles (host guarantees K % 64 == 0, K >= 128)
 
-  // ---- tile of this workgroup (static: one tile; dynamic: queue entry blockIdx.x >> 3 of XCD queue blockIdx.x & 7 first, see gemm8p.h)
-  const bool dyn = gall.sched != nullptr;    // scalar
-  const int qx = blockIdx.x & 7;
-  const int q_cnt = (ntiles >> 3) + (qx < (ntiles & 7) ? 1 : 0);
-  const int q_start = xcd_remap(qx, ntiles);
-  const int q_wgs = ((int)gridDim.x >> 3) + (qx < ((int)gridDim.x & 7) ? 1 : 0);
-  int logical = xcd_remap((int)blockIdx.x, ntiles);
+  // ---- tile of this workgroup, its group's operands (grouped launch), buffer descriptors
   GemmArgs g = gall;                         // (scalar fields only are ever read through this copy)
+  int tm, tn;
+  tile_of(xcd_remap((int)blockIdx.x, ntiles), gall.tiles_m, gall.tiles_n, gall.group_m, tm, tn);
+  if (gall.ngroups > 1) {
+    const int gi = tm / gall.group_tiles_m;
+    tm -= gi * gall.group_tiles_m;
+    select_group(g, gall, gi);
+  }
+  const int m0 = tm * 256, n0 = tn * 128;
   Gemm4wSrc src;
-  int m0, n0;
-  gemm4w_tile(gall, logical, g, src, m0, n0);
+  {
+    const bf16* A = static_cast<const bf16*>(g.A);
+    const bf16* B = static_cast<const bf16*>(g.B);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int ra = g.M - (m0 + 128 * h);
+      const unsigned na = ra <= 0 ? 0u : (unsigned)min(ra, 128) * (unsigned)g.lda * 2u;
+      src.a[h] = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A + (size_t)(m0 + 128 * h) * g.lda), 0, na, 0x00020000);
+    }
+    const int rb = g.N - n0;
+    const unsigned nb = rb <= 0 ? 0u : (unsigned)min(rb, 128) * (unsigned)g.ldb * 2u;
+    src.b = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(B + (size_t)n0 * g.ldb), 0, nb, 0x00020000);
+    src.none = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(A), 0, 0, 0x00020000);
+  }
   // ---- global -> LDS addressing.  LDS row r of a half tile holds 128 bytes of k, chunk c stored at c ^ (r & 7).
   //  A half ha : LDS row r <-> C row    m0 + 128 ha + r                         (wave wr reads rows 64 wr + 16 i + li)
   //  B         : LDS row r = 64 hb + r' <-> C column n0 + 64 (r' >> 5) + 4 (r' & 15) + 2 hb + ((r' >> 4) & 1)
@@ -127,7 +135,14 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
     const int col = 64 * (rp >> 5) + 4 * (rp & 15) + 2 * hb + ((rp >> 4) & 1);
     src.vb[q] = (unsigned)col * (unsigned)gall.ldb * 2u + (unsigned)c * 16u;
   }
-  gemm4w_prologue(lds, src, wave, nt);
+  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);   // (older than every half-tile request)
+
+  // ---- prologue: half tiles s = 0 .. 4  (B0 A0_0 A1_0 | B1 A0_1)
+  stage4w<0>(lds, 0, src, wave, 0, true);
+  stage4w<1>(lds, 1, src, wave, 0, true);
+  stage4w<2>(lds, 2, src, wave, 0, true);
+  stage4w<0>(lds, 3, src, wave, 128, nt > 1);
+  stage4w<1>(lds, 4, src, wave, 128, nt > 1);
 
   // ---- fragment read addresses (bytes): row * 128 + ((4 ks + lg) ^ (row & 7)) * 16; + slot base and 16-row-tile immediates
   const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
@@ -139,13 +154,8 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
     boff[ks] = lds0 + (unsigned)(wc * 32 + li) * 128u + sw;
   }
 
-  int epi_ops = 0;                           // vector-memory operations of the previous tile's epilogue (0: first tile / guarded path)
-  for (;;) {                                 // ---- one output tile per iteration
   unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;  // diagnostic runs only (tools/gemm_timeline.py)
   if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
-  unsigned drawn = 0;
-  if (dyn && tid == 0) drawn = __hip_atomic_fetch_add(gall.sched + qx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
   f32x4 acc[2][2][4][2];                     // [A half][B half][16-row tile][16-column tile]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -158,13 +168,7 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
 
   // (starting the workgroup in the odd hardware wave slot half a phase late - the two workgroups of a CU that start together
   //  might run phase-locked - was measured: no effect at 4096^3, +2 % at K = 2304 / 3072, -5..7 % at K = 768; not kept)
-  // B0, A0_0, A1_0 have landed (this wave's pieces).  Issue order: [5 half tiles = 20 requests | previous epilogue (epi_ops) | draw,
-  // bias]: they are complete once at most the youngest 8 + epi_ops operations are pending (the counter holds 6 bits).
-  if (epi_ops == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  else if (epi_ops == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");
-  else if (epi_ops == 48) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");
-  else if (epi_ops == 64) asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // B0, A0_0, A1_0 have landed (this wave's pieces) ...
   __builtin_amdgcn_s_barrier();                                // ... everybody's
   if (g.dbg) t_loop = __builtin_amdgcn_s_memrealtime();
 
@@ -289,35 +293,8 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
 #undef MISSM_4W_FENCE_A
 #undef MISSM_4W_FENCE_AB
   if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
-  // every fragment read of this tile is complete and everybody is past the last barrier: all five slots are free.  The drawn queue
-  // entry travels through the first word of the (idle) ring - there is no LDS byte to spare at two workgroups per CU -, a second
-  // barrier keeps the next tile's requests behind everybody's read of it.
-  bool more = false;                         // wave-uniform
-  int nlogical = 0;
-  if (dyn) {
-    // (the word lies in wave 0's piece of slot 0: its last - dropped, zero-filling - requests must have landed before it is written)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (tid == 0) *reinterpret_cast<volatile unsigned*>(lds) = drawn;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const unsigned d = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(lds));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    const int k = q_wgs + (int)d;
-    more = k < q_cnt;
-    nlogical = q_start + k;
-    if ((int)d == q_cnt - 1 && tid == 0) __hip_atomic_store(gall.sched + qx, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (more) {
-      GemmArgs gn = gall;
-      Gemm4wSrc srcn = src;
-      int m0n, n0n;
-      gemm4w_tile(gall, nlogical, gn, srcn, m0n, n0n);
-      gemm4w_prologue(lds, srcn, wave, nt);
-    }
-  }
 
-  epi_ops = gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4);
-  if (epi_ops < 0) {
+  if (gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4) < 0) {
 #pragma unroll
     for (int ha = 0; ha < 2; ++ha) {
       typename AuxPre<bf16>::V upre[4][4];
@@ -332,16 +309,258 @@ __global__ __launch_bounds__(256, 2) void gemm4w_kernel(GemmArgs gall) {
   }
   if (g.dbg && tid == 0) {
     const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
-    unsigned long long* d = g.dbg + (size_t)logical * 8;
+    unsigned long long* d = g.dbg + (size_t)blockIdx.x * 8;
     d[0] = t_start; d[1] = t_loop; d[2] = t_loop_end; d[3] = t_issued;
     d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[5] = t_issued; d[6] = t_loop_end;
     d[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15;    // XCC id
   }
-  if (!more) break;
-  logical = nlogical;
-  g = gall;
-  gemm4w_tile(gall, logical, g, src, m0, n0);
-  }                                          // ---- next tile
+}
+
+// =====================================================================================================================
+// CONTINUOUS form (round 3): 512 resident workgroups (two per CU) walk the tiles b, b + 512, ... and the K loop RUNS ON ACROSS TILE
+// BOUNDARIES - the half tiles behind a tile's last K tile are the next tile's first ones, so the ring never drains, there is no
+// prologue burst and no relaunch.  Why: in-kernel stamps of the one-tile form (tools/gemm_timeline.py) show a 12.7 us main loop and a
+// 4.5 us epilogue per 256 x 128 tile with two tiles in flight per CU - 15 % less CU time per output than the 8-phase kernel, whose
+// epilogue (store path: 34 - 52 GB/s per CU) is serial with its main loop - and then 3.5 - 5 us of EMPTY slot between two workgroups
+// (a workgroup retires when its stores have drained, its successor starts cold): 121 us of work in a 157 us QKV launch.  A resident
+// grid that requests the next tile's five prologue half tiles before the epilogue (MISSM_GEMM_PERSIST4W) was slower still: twenty
+// requests per wave queued in front of the sixteen stores.  Here only the two requests of the next K tile's phase 0 stand in front of
+// the stores (their slots are free: the fragments they held are in registers), and the epilogue's operations are counted into the two
+// waits that follow it (loads and stores share vmcnt in issue order on gfx950: a wait for a load younger than the stores is a wait for
+// the stores; the first such wait comes one and a half K tiles after the epilogue).
+// Request schedule in global K-tile numbers g (phase 0 of g: A1(g + 1), B(g + 2); phase 1: A0(g + 2)); at a tile's first K tile g0
+// phase 0 requests nothing - its two requests were issued in front of the previous epilogue:
+//   ... phase 1 (g0 - 1): A0(g0 + 1) | barrier | A1(g0 + 1), B(g0 + 2) | EPILOGUE (E operations) | bias | phase 0 (g0): - | W0 | phase 1
+//   (g0): A0(g0 + 2) | W1 | phase 0 (g0 + 1): A1(g0 + 2), B(g0 + 3) | W2 ...
+//   W0 needs A0(g0 + 1): younger = 8 + E (+ bias) -> vmcnt(8 + E); W1 needs A1(g0 + 1): younger = 4 + E + 4 -> vmcnt(8 + E); W2 = vmcnt(8).
+// The fragments of the next tile's first K tile (A0, B: read one phase ahead as always) stay in registers across the epilogue.
+// Host guarantees: K % 64 == 0, K >= 192 (three K tiles: the requests two K tiles ahead never reach past the NEXT tile).
+// =====================================================================================================================
+__global__ __launch_bounds__(256, 2) void gemm4wc_kernel(GemmArgs gall) {
+  extern __shared__ __attribute__((aligned(16))) char lds[];   // 5 slots x 16 KiB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int li = lane & 15, lg = lane >> 4;
+  const int ntiles = gall.tiles_m * gall.tiles_n;
+  const int nt = gall.K >> 6;
+
+  int bid = blockIdx.x;                      // hardware-order id of the tile in hand (logical id = xcd_remap(bid))
+  GemmArgs g = gall;
+  Gemm4wSrc src;
+  int m0, n0;
+  gemm4w_tile(gall, xcd_remap(bid, ntiles), g, src, m0, n0);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int r = 32 * wave + 8 * q + (lane >> 3);
+    const int c = (lane & 7) ^ (r & 7);
+    src.va[q] = (unsigned)r * (unsigned)gall.lda * 2u + (unsigned)c * 16u;
+    const int hb = r >> 6, rp = r & 63;
+    const int col = 64 * (rp >> 5) + 4 * (rp & 15) + 2 * hb + ((rp >> 4) & 1);
+    src.vb[q] = (unsigned)col * (unsigned)gall.ldb * 2u + (unsigned)c * 16u;
+  }
+  gemm4w_prologue(lds, src, wave, nt);
+
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)lds;
+  unsigned aoff[2], boff[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const unsigned sw = (unsigned)(((ks * 4 + lg) ^ (li & 7)) << 4);
+    aoff[ks] = lds0 + (unsigned)(wr * 64 + li) * 128u + sw;
+    boff[ks] = lds0 + (unsigned)(wc * 32 + li) * 128u + sw;
+  }
+  // the tile after this one (descriptors kept in scalar registers: the K loop requests from it behind its last two K tiles)
+  int nbid = bid + (int)gridDim.x;
+  bool more = nbid < ntiles;                 // wave-uniform
+  GemmArgs gn = gall;
+  Gemm4wSrc srcn = src;
+  int m0n = 0, n0n = 0;
+  if (more) gemm4w_tile(gall, xcd_remap(nbid, ntiles), gn, srcn, m0n, n0n);
+
+  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");             // B0, A0_0, A1_0 of the first tile have landed (this wave's pieces) ...
+  __builtin_amdgcn_s_barrier();                                // ... everybody's
+
+  bf16x8 fa[2][4][2], fb[2][2][2];           // A fragments, double-buffered [buffer][i][ks]; B [hb][j][ks]
+#define MISSM_4W_READ_A(SLOT, BUF)                                                            \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+    const unsigned ad = aoff[ks] + (unsigned)(SLOT) * 16384u;                                 \
+    fa[BUF][0][ks] = lds_read128<0 * 2048>(ad);                                               \
+    fa[BUF][1][ks] = lds_read128<1 * 2048>(ad);                                               \
+    fa[BUF][2][ks] = lds_read128<2 * 2048>(ad);                                               \
+    fa[BUF][3][ks] = lds_read128<3 * 2048>(ad);                                               \
+  }
+#define MISSM_4W_READ_B(SLOT)                                                                 \
+  _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                          \
+    const unsigned bd = boff[ks] + (unsigned)(SLOT) * 16384u;                                 \
+    fb[0][0][ks] = lds_read128<0>(bd);                                                        \
+    fb[0][1][ks] = lds_read128<2048>(bd);                                                     \
+    fb[1][0][ks] = lds_read128<8192>(bd);                                                     \
+    fb[1][1][ks] = lds_read128<8192 + 2048>(bd);                                              \
+  }
+#define MISSM_4W_FENCE_A(BUF)                                                                 \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                         \
+               : "+v"(fa[BUF][0][0]), "+v"(fa[BUF][1][0]), "+v"(fa[BUF][2][0]), "+v"(fa[BUF][3][0]), "+v"(fa[BUF][0][1]),       \
+                 "+v"(fa[BUF][1][1]), "+v"(fa[BUF][2][1]), "+v"(fa[BUF][3][1]));              \
+  __builtin_amdgcn_sched_barrier(0);
+#define MISSM_4W_FENCE_AB(BUF)                                                                \
+  asm volatile("s_waitcnt lgkmcnt(0)"                                                         \
+               : "+v"(fa[BUF][0][0]), "+v"(fa[BUF][1][0]), "+v"(fa[BUF][2][0]), "+v"(fa[BUF][3][0]), "+v"(fa[BUF][0][1]),       \
+                 "+v"(fa[BUF][1][1]), "+v"(fa[BUF][2][1]), "+v"(fa[BUF][3][1]), "+v"(fb[0][0][0]), "+v"(fb[0][1][0]),          \
+                 "+v"(fb[1][0][0]), "+v"(fb[1][1][0]), "+v"(fb[0][0][1]), "+v"(fb[0][1][1]), "+v"(fb[1][0][1]), "+v"(fb[1][1][1])); \
+  __builtin_amdgcn_sched_barrier(0);
+#define MISSM_4W_MF(HA, BUF, N)                                                               \
+  {                                                                                           \
+    constexpr int ks_ = (N) >> 4, i_ = ((N) >> 2) & 3, hb_ = ((N) >> 1) & 1, j_ = (N) & 1;       \
+    acc[HA][hb_][i_][j_] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[BUF][i_][ks_], fb[hb_][j_][ks_], acc[HA][hb_][i_][j_], 0, 0, 0); \
+  }
+#define MISSM_4W_RA(SLOT, BUF, R)                                                             \
+  {                                                                                           \
+    constexpr int ks_ = (R) >> 2, i_ = (R) & 3;                                               \
+    fa[BUF][i_][ks_] = lds_read128<i_ * 2048>(aoff[ks_] + (unsigned)(SLOT) * 16384u);         \
+  }
+#define MISSM_4W_RB(SLOT, R)                                                                  \
+  {                                                                                           \
+    constexpr int ks_ = (R) >> 2, hb_ = ((R) >> 1) & 1, j_ = (R) & 1;                          \
+    fb[hb_][j_][ks_] = lds_read128<hb_ * 8192 + j_ * 2048>(boff[ks_] + (unsigned)(SLOT) * 16384u); \
+  }
+// wait for everything but the youngest 8 requests and the E operations of the epilogue that lies between them and the target
+#define MISSM_4W_WAIT(E)                                                                      \
+  if ((E) == 0) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                              \
+  else if ((E) == 16) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");                       \
+  else if ((E) == 32) asm volatile("s_waitcnt vmcnt(40)" ::: "memory");                       \
+  else if ((E) == 48) asm volatile("s_waitcnt vmcnt(56)" ::: "memory");                       \
+  else asm volatile("s_waitcnt vmcnt(63)" ::: "memory");
+
+  int sB = 0, sA0 = 1, sA1 = 2;              // slots of the K tile in hand: (3 g + h) mod 5, g counted over ALL tiles of this workgroup
+  MISSM_4W_READ_B(sB)
+  MISSM_4W_READ_A(sA0, 0)
+  MISSM_4W_FENCE_AB(0)
+  __builtin_amdgcn_s_barrier();              // B(0), A0(0) are in registers everywhere: their slots are free
+  // phase 0 requests of the first K tile: A1(1) -> B(0)'s slot, B(2) -> A0(0)'s slot (K >= 192: both in this tile)
+  stage4w<2>(lds, sB, src, wave, 128, true);
+  stage4w<0>(lds, sA0, src, wave, 256, true);
+  int epi = 0;                               // vector-memory operations of the epilogue in front of this tile's first K tile
+
+  for (;;) {                                 // ---- one output tile per iteration
+    unsigned long long t_start = 0, t_loop_end = 0;
+    if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
+    f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
+    f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[a][b][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int t = 0; t < nt; ++t) {
+      // K tiles t + 1 and t + 2 of this tile - or the first ones of the next tile
+      const bool in1 = t + 1 < nt, in2 = t + 2 < nt;
+      const int kb1 = (in1 ? t + 1 : t + 1 - nt) * 128, kb2 = (in2 ? t + 2 : t + 2 - nt) * 128;
+      const bool live1 = in1 || more, live2 = in2 || more;
+      const __amdgpu_buffer_rsrc_t rA1_1 = live1 ? (in1 ? src.a[1] : srcn.a[1]) : src.none;     // A1(t + 1)
+      const __amdgpu_buffer_rsrc_t rB_2 = live2 ? (in2 ? src.b : srcn.b) : src.none;           // B(t + 2)
+      const __amdgpu_buffer_rsrc_t rA0_2 = live2 ? (in2 ? src.a[0] : srcn.a[0]) : src.none;     // A0(t + 2)
+      using lptr = __attribute__((address_space(3))) void*;
+      const int nB = sB + 3 >= 5 ? sB - 2 : sB + 3, nA0 = sA0 + 3 >= 5 ? sA0 - 2 : sA0 + 3, nA1 = sA1 + 3 >= 5 ? sA1 - 2 : sA1 + 3;
+      char* const dB = lds + sB * 16384 + wave * 4096;
+      char* const dA0 = lds + sA0 * 16384 + wave * 4096;
+      char* const dA1 = lds + sA1 * 16384 + wave * 4096;
+      const bool first = t == 0;             // phase 0 of a tile's first K tile requests nothing (issued in front of the epilogue)
+      // ---- phase 0: A half 0 x B.  Side: requests A1(t + 1) -> B(t)'s slot, B(t + 2) -> A0(t)'s slot; reads of A1(t)
+      __builtin_amdgcn_s_setprio(1);
+      static_for<0, 32>([&](auto n_) {
+        constexpr int n = decltype(n_)::value;
+        MISSM_4W_MF(0, 0, n)
+        if constexpr (n % 2 == 1) {
+          constexpr int k = n / 2;
+          if constexpr (k % 2 == 0) {
+            if (!first) {
+              if constexpr (k / 2 < 4) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA1_1, (lptr)(dB + (k / 2) * 1024), 16, src.va[k / 2], kb1, 0, 0);
+              else __builtin_amdgcn_raw_ptr_buffer_load_lds(rB_2, (lptr)(dA0 + (k / 2 - 4) * 1024), 16, src.vb[k / 2 - 4], kb2, 0, 0);
+            }
+          } else {
+            MISSM_4W_RA(sA1, 1, k / 2)
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      __builtin_amdgcn_s_setprio(0);
+      MISSM_4W_FENCE_A(1)
+      if (first) { MISSM_4W_WAIT(epi) } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 1: A half 1 x B.  Side: request A0(t + 2) -> A1(t)'s slot, reads of A0(t + 1), then of B(t + 1)
+      __builtin_amdgcn_s_setprio(1);
+      static_for<0, 32>([&](auto n_) {
+        constexpr int n = decltype(n_)::value;
+        MISSM_4W_MF(1, 1, n)
+        if constexpr (n % 2 == 1) {
+          constexpr int k = n / 2;
+          if constexpr (k < 8) {
+            if constexpr (k % 2 == 0) __builtin_amdgcn_raw_ptr_buffer_load_lds(rA0_2, (lptr)(dA1 + (k / 2) * 1024), 16, src.va[k / 2], kb2, 0, 0);
+            else MISSM_4W_RA(nA0, 0, k / 2)
+          } else {
+            if constexpr (k % 2 == 0) MISSM_4W_RA(nA0, 0, 4 + (k - 8) / 2)
+            else MISSM_4W_RB(nB, (k - 8) / 2)
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      });
+      __builtin_amdgcn_s_setprio(0);
+      MISSM_4W_RB(nB, 4) MISSM_4W_RB(nB, 5) MISSM_4W_RB(nB, 6) MISSM_4W_RB(nB, 7)
+      MISSM_4W_FENCE_AB(0)
+      if (first) { MISSM_4W_WAIT(epi) } else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      sB = nB; sA0 = nA0; sA1 = nA1;
+    }
+    if (g.dbg) t_loop_end = __builtin_amdgcn_s_memrealtime();
+    asm volatile("" : "+v"(bias4));            // (the compiler's wait for the bias vector lands here, not behind the requests below)
+    // The next tile's A0(0) / B(0) fragments are in registers, their slots free: its phase 0 requests go out in front of the stores.
+    if (more) {
+      stage4w<2>(lds, sB, srcn, wave, 128, true);
+      stage4w<0>(lds, sA0, srcn, wave, 256, true);
+    }
+    epi = gemm8p_store_tile(g, acc, m0 + 64 * wr, n0 + 64 * wc, lane, bias4);
+    if (epi < 0) {
+      epi = 0;                               // (guarded path: an unknown number of operations - wait for all of them)
+#pragma unroll
+      for (int ha = 0; ha < 2; ++ha) {
+        typename AuxPre<bf16>::V upre[4][4];
+        f32x4 blk[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          blk[i][0] = acc[ha][0][i][0]; blk[i][1] = acc[ha][0][i][1];
+          blk[i][2] = acc[ha][1][i][0]; blk[i][3] = acc[ha][1][i][1];
+        }
+        gemm_epilogue<bf16, false, false>(g, blk, m0 + 128 * ha + 64 * wr, n0 + 64 * wc, 0, lane, bias4, nullptr, upre, false);
+      }
+    }
+    if (g.dbg && tid == 0) {
+      const unsigned long long t_issued = __builtin_amdgcn_s_memrealtime();
+      unsigned long long* d = g.dbg + (size_t)xcd_remap(bid, ntiles) * 8;
+      d[0] = t_start; d[1] = t_start; d[2] = t_loop_end; d[3] = t_issued;
+      d[4] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11)); d[5] = t_issued; d[6] = t_loop_end;
+      d[7] = __builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (31 << 11)) & 15;
+    }
+    if (!more) break;
+    bid = nbid;
+    g.A = gn.A; g.B = gn.B; g.C = gn.C; g.bias = gn.bias; g.resid = gn.resid; g.aux_in = gn.aux_in; g.aux_out = gn.aux_out;
+    src.a[0] = srcn.a[0]; src.a[1] = srcn.a[1]; src.b = srcn.b;
+    m0 = m0n; n0 = n0n;
+    nbid = bid + (int)gridDim.x;
+    more = nbid < ntiles;
+    if (more) { gn = gall; gemm4w_tile(gall, xcd_remap(nbid, ntiles), gn, srcn, m0n, n0n); }
+  }
+#undef MISSM_4W_MF
+#undef MISSM_4W_RA
+#undef MISSM_4W_RB
+#undef MISSM_4W_READ_A
+#undef MISSM_4W_READ_B
+#undef MISSM_4W_FENCE_A
+#undef MISSM_4W_FENCE_AB
+#undef MISSM_4W_WAIT
 }
 
 }  // namespace missm

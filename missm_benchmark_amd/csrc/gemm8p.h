@@ -122,8 +122,13 @@ __device__ __forceinline__ void store_wide_bf16(__amdgpu_buffer_rsrc_t rsrc, uns
   const u32x2 r0 = {dpp_swap1(s0[0]), dpp_swap1(s0[1])}, r1 = {dpp_swap1(s1[0]), dpp_swap1(s1[1])};
   const u32x4 w0 = odd ? u32x4{r0[0], r0[1], k0[0], k0[1]} : u32x4{k0[0], k0[1], r0[0], r0[1]};
   const u32x4 w1 = odd ? u32x4{r1[0], r1[1], k1[0], k1[1]} : u32x4{k1[0], k1[1], r1[0], r1[1]};
-  __builtin_amdgcn_raw_buffer_store_b128(w0, rsrc, voff, soff, AUXBITS);
-  __builtin_amdgcn_raw_buffer_store_b128(w1, rsrc, voff + pitch, soff, AUXBITS);
+  // soffset stays the literal 0 and the tile's scalar row offset goes into the lane offset: with a REGISTER in the soffset field hipcc
+  // assumes that a store's data registers may be rewritten by the very next instruction (GCNHazardRecognizer: "this hazard only exists
+  // if the instruction is not using a register in the soffset field") - on gfx950 the first data register of a 16-byte store was then
+  // overwritten before the last lanes had been read (round 3, once the waterfall loops that used to separate store and overwrite were
+  // gone: component 0 of rows r = 0..2, lanes 12-15 of every 16, in tiles here and there; found with an all-rows parity check).
+  __builtin_amdgcn_raw_buffer_store_b128(w0, rsrc, voff + soff, 0, AUXBITS);
+  __builtin_amdgcn_raw_buffer_store_b128(w1, rsrc, voff + pitch + soff, 0, AUXBITS);
 }
 
 __device__ __forceinline__ u32x2 pack_bf16x4(f32x4 v) {
@@ -192,7 +197,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
         for (int r = 0; r < 4; ++r) {
           f32x4 v = MISSM_VAL(ch >> 2, ch & 3, r);
           v += __builtin_bit_cast(f32x4, q[ch & 1][r]);
-          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ch >> 2, ch & 3), MISSM_EPI_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r] + MISSM_SC(ch >> 2, ch & 3), 0, MISSM_EPI_AUX);   // (soffset 0: see store_wide_bf16)
         }
       }
     } else {
@@ -203,7 +208,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const f32x4 v = MISSM_VAL(ha, i, r);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r], MISSM_SC(ha, i), MISSM_EPI_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), e.c, vcr[r] + MISSM_SC(ha, i), 0, MISSM_EPI_AUX);
           }
     }
   } else {
@@ -248,16 +253,27 @@ __device__ __forceinline__ int gemm8p_store_tile(const GemmArgs& g, const f32x4 
   const bool fast = mode >= 0 && g.vec_ok && !g.accumulate && nw + 64 <= g.N && (mode != 2 || has_aux) && (mode == 3 || !g.resid) &&
                     (size_t)g.M * g.ldc * esz < (size_t(1) << 32) && (size_t)g.M * g.ldaux * 2 < (size_t(1) << 32);
   if (!fast) return -1;
+  // Every descriptor input goes through readfirstlane: in the resident kernels the tile's pointers and origin are loop-carried, hipcc
+  // then keeps them in VECTOR registers and wraps EVERY buffer operation of the epilogue in a waterfall loop (readfirstlane x 4, compare,
+  // saveexec, the operation, loop: 195 of them in the 8-phase kernel since round 2 made its grid resident - found in the .s in round 3).
+  auto uptr = [](const void* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+#ifdef MISSM_X_WATERFALL
+    return reinterpret_cast<char*>(v);
+#else
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo);
+#endif
+  };
+  mwb = __builtin_amdgcn_readfirstlane(mwb);
   Epi8p e;
-  e.pitch_c = (unsigned)g.ldc * esz; e.pitch_aux = (unsigned)g.ldaux * 2u;
-  const unsigned rows = (unsigned)min(max(g.M - mwb, 0), 192);
-  char* cb = static_cast<char*>(g.C) + (size_t)mwb * e.pitch_c;
+  e.pitch_c = (unsigned)__builtin_amdgcn_readfirstlane(g.ldc * esz); e.pitch_aux = (unsigned)__builtin_amdgcn_readfirstlane(g.ldaux * 2);
+  const unsigned rows = (unsigned)__builtin_amdgcn_readfirstlane(min(max(g.M - mwb, 0), 192));
+  char* cb = uptr(g.C) + (size_t)mwb * e.pitch_c;
   e.c = __builtin_amdgcn_make_buffer_rsrc(cb, 0, rows * e.pitch_c, 0x00020000);
-  e.res = g.resid ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.resid)) + (size_t)mwb * e.pitch_c, 0,
-                                                      rows * e.pitch_c, 0x00020000)
+  e.res = g.resid ? __builtin_amdgcn_make_buffer_rsrc(uptr(g.resid) + (size_t)mwb * e.pitch_c, 0, rows * e.pitch_c, 0x00020000)
                   : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
-  e.aux = has_aux ? __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(static_cast<const char*>(auxp)) + (size_t)mwb * e.pitch_aux, 0,
-                                                      rows * e.pitch_aux, 0x00020000)
+  e.aux = has_aux ? __builtin_amdgcn_make_buffer_rsrc(uptr(auxp) + (size_t)mwb * e.pitch_aux, 0, rows * e.pitch_aux, 0x00020000)
                   : __builtin_amdgcn_make_buffer_rsrc(cb, 0, 0, 0x00020000);
   e.vc = (unsigned)(lg * 4) * e.pitch_c + (unsigned)(nw + li * 4) * esz;
   e.vaux = (unsigned)(lg * 4) * e.pitch_aux + (unsigned)(nw + li * 4) * 2u;
@@ -342,9 +358,22 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   for (;;) {                                 // ---- one output tile per iteration
   unsigned long long t_start = 0, t_loop = 0, t_loop_end = 0;       // diagnostic runs only (tools/gemm_timeline.py)
   if (g.dbg) t_start = __builtin_amdgcn_s_memrealtime();
+  // The draw is a BUFFER atomic that every lane executes with only thread 0 in range (a 4-byte descriptor: the others are dropped by
+  // the range check and return 0): no branch, no phi - the compiler keeps the result pending and waits for it at its first use, behind
+  // the main loop.  (The plain builtin atomic under `if (tid == 0)` is rewritten by hipcc's atomic optimizer into a wave-aggregated one
+  // whose result it needs on the spot: s_waitcnt vmcnt(0) at the top of the tile, behind every store of the previous epilogue and this
+  // tile's fourteen requests.  An inline-assembly atomic is no way out either: the compiler copies its output register while the
+  // value is still in flight - tiles were drawn twice and skipped.)
   unsigned drawn = 0;
+#ifdef MISSM_X_OLDDRAW
   if (dyn && tid == 0) drawn = __hip_atomic_fetch_add(gall.sched + qx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
+#else
+  if (dyn) {
+    const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(gall.sched + qx, 0, 4, 0x00020000);
+    drawn = (unsigned)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, qr, tid == 0 ? 0 : 64, 0, 0);
+  }
+#endif
+  f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
   f32x4 acc[2][2][4][2];                     // [A half][B half][16-row tile][16-column tile]
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -359,6 +388,9 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   // tiles AND the epilogue's stores stay in flight (round 2 waited vmcnt(6) here, i.e. for every store of the epilogue to be
   // acknowledged: that wait was the persistent grid's whole loss against a relaunch).  The counter holds 6 bits: 63 is still a
   // lower bound on what is younger than K tile 0 when epi_ops = 64.
+#ifdef MISSM_X_TOPDRAIN
+  if (epi_ops != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else
+#endif
   if (epi_ops == 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
   else if (epi_ops == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
   else if (epi_ops == 48) asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
@@ -452,8 +484,14 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
 #undef MISSM_8P_READ_A
 #undef MISSM_8P_READ_B
 #undef MISSM_8P_FENCE_ALL
+  // (the compiler waits for the bias vector at its first use; in the epilogue that wait was vmcnt(0) - behind the next tile's fourteen
+  //  requests.  Using it here, where nothing but dropped requests is pending, leaves the epilogue without that wait.)
+#ifndef MISSM_X_NOBIASASM
+  asm volatile("" : "+v"(bias4));
+#endif
   if (dyn) {                                 // the draw went out a whole main loop ago: hand it to the other waves through LDS
-    if (tid == 0) *reinterpret_cast<volatile unsigned*>(lds + 131072) = drawn;
+    using ldsw = volatile __attribute__((address_space(3))) unsigned*;
+    if (tid == 0) *(ldsw)(lds + 131072) = drawn;
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (!STAGGER) __builtin_amdgcn_s_barrier();
   }
@@ -464,7 +502,11 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   int nbid = bid + (int)gridDim.x, nlogical;
   bool more;                                 // wave-uniform
   if (dyn) {
-    const unsigned d = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile unsigned*>(lds + 131072));
+    using ldsw = volatile __attribute__((address_space(3))) unsigned*;
+#ifdef MISSM_X_PREDRAIN
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+    const unsigned d = __builtin_amdgcn_readfirstlane(*(ldsw)(lds + 131072));
     const int k = q_wgs + (int)d;            // queue entry (entries 0 .. q_wgs - 1 were the static first tiles)
     more = k < q_cnt;
     nlogical = q_start + k;
