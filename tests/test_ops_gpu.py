@@ -609,6 +609,12 @@ def test_gemm_tile_kernels_on_the_step_shapes():
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_nt_ab.py")], capture_output=True, text=True, timeout=900,
                              env=dict(os.environ, MISSM_GEMM_4W=knob), cwd=root)
         assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+    # the other tile schedules of the 8-phase kernel (one workgroup per tile, resident grid in static order; the default - resident grid
+    # drawing tiles from per-XCD queues - ran above) and the K-continuous resident form of the 256 x 128 kernel, on the video-tower shapes
+    for env in (dict(MISSM_GEMM_PERSIST="0"), dict(MISSM_GEMM_PERSIST="1"), dict(MISSM_GEMM_4W="2", MISSM_GEMM_4WC="1")):
+        out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_nt_ab.py"), "vid", "4x"], capture_output=True, text=True, timeout=900,
+                             env=dict(os.environ, **env), cwd=root)
+        assert out.returncode == 0 and "ALL OK" in out.stdout, str(env) + out.stdout[-3000:] + out.stderr[-2000:]
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "gemm_tn_ab.py")], capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
 
