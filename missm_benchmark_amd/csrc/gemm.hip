@@ -922,6 +922,8 @@ int tile_queue_counters(void* stream, unsigned** sched) {
 }
 }  // namespace
 
+int missm_stream_workspace(void* stream, size_t bytes, float** ws) { return splitk_workspace(stream, bytes, ws); }
+
 extern "C" void missm_gemm_release_workspaces(void) {
   std::lock_guard<std::mutex> lk(g_ws_mu);
   (void)hipDeviceSynchronize();

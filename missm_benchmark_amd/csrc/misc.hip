@@ -340,6 +340,82 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(const float* __restrict__
   if (threadIdx.x == 0) *loss = ((red[0] + red[1]) + (red[2] + red[3])) / (float)n;
 }
 
+// ---- the same two losses for LARGE inputs (per-token features, big batches): the one-workgroup kernels above walk every row / element
+// from a single CU.  Rows / chunks are spread over the chip, partial sums go through the stream's scratch and are added up
+// in a FIXED order by one workgroup: still bit-reproducible.
+__global__ __launch_bounds__(256) void mask_count_kernel(const unsigned char* __restrict__ mask, int B, float* __restrict__ cnt) {
+  __shared__ float red[4];
+  float c = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) c += (!mask || mask[b]) ? 1.f : 0.f;
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) *cnt = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// one wave per row: lanes stride over the row's C columns
+__global__ __launch_bounds__(256) void kl_rows_kernel(const float* __restrict__ s, const float* __restrict__ t, const unsigned char* __restrict__ mask,
+                                                     const float* __restrict__ cnt, float* __restrict__ part, float* __restrict__ ds, int B, int C,
+                                                     float inv_temp) {
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (b >= B) return;
+  const bool on = !mask || mask[b];
+  const float* sr = s + (long)b * C;
+  const float* tr = t + (long)b * C;
+  float p = 0.f;
+  if (on) {
+    float ms = -__builtin_huge_valf(), mt = ms;
+    for (int c = lane; c < C; c += 64) { ms = fmaxf(ms, sr[c] * inv_temp); mt = fmaxf(mt, tr[c] * inv_temp); }
+    ms = wave_max(ms); mt = wave_max(mt);
+    float zs = 0.f, zt = 0.f;
+    for (int c = lane; c < C; c += 64) { zs += expf(sr[c] * inv_temp - ms); zt += expf(tr[c] * inv_temp - mt); }
+    const float ls = ms + logf(wave_sum(zs)), lt = mt + logf(wave_sum(zt));
+    const float n = *cnt;
+    for (int c = lane; c < C; c += 64) {
+      const float lps = sr[c] * inv_temp - ls, lpt = tr[c] * inv_temp - lt;
+      const float pt = expf(lpt);
+      p += pt > 0.f ? pt * (lpt - lps) : 0.f;
+      if (ds) ds[(long)b * C + c] = (expf(lps) - pt) * inv_temp / n;
+    }
+    p = wave_sum(p);
+  } else if (ds) {
+    for (int c = lane; c < C; c += 64) ds[(long)b * C + c] = 0.f;
+  }
+  if (lane == 0) part[b] = p;
+}
+
+// loss = (sum of n partials, fixed order) * scale / (*div or 1)
+__global__ __launch_bounds__(256) void ordered_sum_kernel(const float* __restrict__ part, long n, const float* __restrict__ div, float scale,
+                                                         float* __restrict__ loss) {
+  __shared__ float red[256];
+  float a = 0.f;
+  for (long i = threadIdx.x; i < n; i += 256) a += part[i];
+  red[threadIdx.x] = a;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *loss = red[0] * scale / (div ? *div : 1.f);
+}
+
+// chunk c of `per` elements: partial sum of squares in a fixed order, da written on the way
+__global__ __launch_bounds__(256) void mse_chunks_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ part,
+                                                        float* __restrict__ da, long n, long per) {
+  __shared__ float red[4];
+  const long lo = (long)blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  float p = 0.f;
+  for (long i = lo + threadIdx.x; i < hi; i += 256) {
+    const float d = a[i] - b[i];
+    p += d * d;
+    if (da) da[i] = 2.f * d / (float)n;
+  }
+  p = wave_sum(p);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = p;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
 // teacher EMA of the MTD student mode (train_ddp.py:256-259): tea = decay * tea + (1 - decay) * stu
 __global__ __launch_bounds__(256) void ema_kernel(float* __restrict__ tea, const float* __restrict__ stu, long n, float decay) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) tea[i] = tea[i] * decay + stu[i] * (1.f - decay);
@@ -722,12 +798,29 @@ extern "C" int missm_cross_entropy(const float* logits, const long* labels, floa
 extern "C" int missm_kl_loss(const float* student, const float* teacher, const unsigned char* row_mask, float* loss, float* dstudent, int B,
                              int C, float temperature, void* stream) {
   MISSM_CHECK_ARG(B > 0 && C > 0 && temperature > 0.f, "kl_loss: bad shape");
+  if ((long)B * C > (1L << 16)) {           // large inputs: one wave per row over the whole chip, ordered second stage
+    float* ws = nullptr;
+    if (missm_stream_workspace(stream, ((size_t)B + 64) * sizeof(float), &ws)) { missm_set_error("kl_loss: cannot allocate scratch"); return MISSM_ERR_LAUNCH; }
+    hipLaunchKernelGGL(mask_count_kernel, dim3(1), dim3(256), 0, S_(stream), row_mask, B, ws);
+    hipLaunchKernelGGL(kl_rows_kernel, dim3((B + 3) / 4), dim3(256), 0, S_(stream), student, teacher, row_mask, ws, ws + 64, dstudent, B, C, 1.0f / temperature);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, S_(stream), ws + 64, (long)B, ws, 1.0f, loss);
+    return missm_check_launch("kl_loss");
+  }
   hipLaunchKernelGGL(kl_loss_kernel, dim3(1), dim3(64), 0, S_(stream), student, teacher, row_mask, loss, dstudent, B, C, 1.0f / temperature);
   return missm_check_launch("kl_loss");
 }
 
 extern "C" int missm_mse_loss(const float* a, const float* b, float* loss, float* da, long n, void* stream) {
   MISSM_CHECK_ARG(n > 0, "mse_loss: empty input");
+  if (n > (1L << 16)) {
+    const long per = 16384;
+    const long chunks = (n + per - 1) / per;
+    float* ws = nullptr;
+    if (missm_stream_workspace(stream, (size_t)chunks * sizeof(float), &ws)) { missm_set_error("mse_loss: cannot allocate scratch"); return MISSM_ERR_LAUNCH; }
+    hipLaunchKernelGGL(mse_chunks_kernel, dim3((unsigned)chunks), dim3(256), 0, S_(stream), a, b, ws, da, n, per);
+    hipLaunchKernelGGL(ordered_sum_kernel, dim3(1), dim3(256), 0, S_(stream), ws, chunks, (const float*)nullptr, 1.0f / (float)n, loss);
+    return missm_check_launch("mse_loss");
+  }
   hipLaunchKernelGGL(mse_loss_kernel, dim3(1), dim3(256), 0, S_(stream), a, b, loss, da, n);
   return missm_check_launch("mse_loss");
 }

@@ -5,6 +5,8 @@
 #include "../../include/missm_hip.h"
 
 void missm_set_error(const char* fmt, ...);
+// per-stream scratch of the library (gemm.hip: the split-K workspace, >= 32 MB, grown on demand; users on one stream are stream-ordered)
+int missm_stream_workspace(void* stream, size_t bytes, float** ws);
 
 #define MISSM_CHECK_ARG(cond, msg)                         \
   do {                                                     \

@@ -687,6 +687,41 @@ def test_distillation_losses_vs_reference_fixture():
     assert float((pt.cpu() - fix["ema"]["out"]).abs().max()) < 1e-6
 
 
+@pytest.mark.parametrize("B,C,masked", [(1500, 96, False), (1500, 96, True), (700, 256, True), (40, 2048, False)])
+def test_kl_and_mse_losses_on_large_inputs(ops, B, C, masked):
+    """The chip-wide paths of the two distillation losses (B x C > 65536: one wave per row / 16 K-element chunks, partial sums added in a
+    fixed order) against the reference formulas - F.kl_div(log_softmax(s / T), softmax(t / T), 'batchmean') over the selected rows
+    (train_ddp.py:70-79,238-240) and nn.MSELoss - values, gradients, zero gradient on unselected rows, bit-reproducible."""
+    T = 3.0
+    s0, t0 = rnd(B, C, seed=1, scale=2.0), rnd(B, C, seed=2, scale=2.0)
+    mask = (torch.rand(B, generator=torch.Generator().manual_seed(3)) < 0.6) if masked else None
+    sr = s0.clone().requires_grad_(True)
+    sel = mask if masked else torch.ones(B, dtype=torch.bool)
+    ref = F.kl_div(F.log_softmax(sr[sel] / T, dim=1), F.softmax(t0[sel] / T, dim=1), reduction="batchmean")
+    ref.backward()
+    outs = []
+    for _ in range(2):
+        loss, ds = torch.zeros(1, device="cuda"), torch.full((B, C), 7.0, device="cuda")
+        ops.kl_loss(dev(s0), dev(t0), loss, ds, T, None if mask is None else dev(mask))
+        outs.append((loss.clone(), ds.clone()))
+    loss, ds = outs[0]
+    assert abs(float(loss) - float(ref)) < 1e-5 * max(1.0, abs(float(ref)))
+    assert rel(ds, sr.grad) < 1e-4
+    if masked:
+        assert float(ds[~dev(mask)].abs().max()) == 0.0
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    a0, b0 = rnd(B, C, seed=4), rnd(B, C, seed=5)
+    ar = a0.clone().requires_grad_(True)
+    mref = F.mse_loss(ar, b0)
+    mref.backward()
+    l1, da = torch.zeros(1, device="cuda"), torch.empty(B, C, device="cuda")
+    ops.mse_loss(dev(a0), dev(b0), l1, da)
+    l2 = torch.zeros(1, device="cuda")
+    ops.mse_loss(dev(a0), dev(b0), l2, None)
+    assert abs(float(l1) - float(mref)) < 1e-5 * float(mref) and torch.equal(l1, l2)
+    assert rel(da, ar.grad) < 1e-5
+
+
 @pytest.mark.parametrize("hw", [(300, 400), (480, 360), (224, 224), (150, 500)])
 def test_gpu_image_and_depth_transforms_vs_oracle(hw):
     """processing.ImageTransform / DepthTransform (uint8 HWC / float32 HW in, pixel_values out: resize of the shorter edge with
