@@ -95,8 +95,11 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 // line in the XCD's L2).  Round 2 measured nt (worse on the whole step); round 3 measured sc1 against the default in alternating runs on
 // one box: 66.93 / 66.98 vs 67.07 / 67.36 ms per step (+0.35 %) - the outputs are far larger than L2 and are next read by another
 // kernel, keeping their lines in L2 only evicts operand panels.  (EXTRA=-DMISSM_EPI_AUX=<n> builds another policy for A/B runs.)
+// [r3, last part] with the waterfall loops gone (section "Branch-free vector epilogue" above: the stores issue back to back) nt wins: 63.54 /
+// 63.26 ms per step against 64.29 / 64.45 / 64.53 for sc1 and 64.41 / 64.57 for the default policy (alternating runs on one box);
+// nt + sc1 (18) and nt on the weight-gradient kernel's parked slices (MISSM_PARK_NT) measured no better than nt alone.
 #ifndef MISSM_EPI_AUX
-#define MISSM_EPI_AUX 16
+#define MISSM_EPI_AUX 2
 #endif
 
 struct Epi8p {
@@ -820,7 +823,13 @@ __global__ __launch_bounds__(512, 2) void gemm8p_tn_kernel(GemmArgs gall) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) mine[(((a * 2 + b) * 4 + i) * 2 + j) * 512] = acc[a][b][i][j];
+        for (int j = 0; j < 2; ++j) {
+#ifdef MISSM_PARK_NT
+          __builtin_nontemporal_store(acc[a][b][i][j], &mine[(((a * 2 + b) * 4 + i) * 2 + j) * 512]);
+#else
+          mine[(((a * 2 + b) * 4 + i) * 2 + j) * 512] = acc[a][b][i][j];
+#endif
+        }
 }
 
 // sums the K slices of gemm8p_tn_kernel in slice order.  One workgroup per (tile, sixteenth): thread t adds up vectors
