@@ -59,6 +59,10 @@ __device__ __forceinline__ void store4(bf16* p, f32x4 v) {
   *reinterpret_cast<bf16x4*>(p) = r;
 }
 
+// streaming (non-temporal) forms: for bytes this kernel touches once and nobody reads again soon
+__device__ __forceinline__ f32x4 load4_nt(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void store4_nt(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
+
 // ---- swizzled LDS addressing --------------------------------------------------------------
 // A tile row holds RB bytes (64, 128 or 256); 16-byte chunk c of row r lives at chunk
 // c ^ (r & min(RB/16-1, 7)).  For RB == 128 this makes both the ds_read_b128 fragment reads

@@ -101,6 +101,10 @@ using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
 #ifndef MISSM_EPI_AUX
 #define MISSM_EPI_AUX 2
 #endif
+// cache policy of the epilogue's once-read operands (saved pre-activation, fp32 residual): nt, 63.38 / 63.68 / 63.69 vs 63.90 / 63.91 / 63.81 ms per step
+#ifndef MISSM_EPI_LOAD_AUX
+#define MISSM_EPI_LOAD_AUX 2
+#endif
 
 struct Epi8p {
   __amdgpu_buffer_rsrc_t c, aux, res;
@@ -165,7 +169,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
 #pragma unroll
       for (int k = 0; k < 8; ++k) {
         const int ha = ch >> 1, i = 2 * (ch & 1) + (k >> 2), r = k & 3;
-        dst[k] = __builtin_amdgcn_raw_buffer_load_b64(e.aux, var[r], MISSM_SA(ha, i), 0);
+        dst[k] = __builtin_amdgcn_raw_buffer_load_b64(e.aux, var[r], MISSM_SA(ha, i), MISSM_EPI_LOAD_AUX);
       }
     };
     request(0, u[0]);
@@ -190,7 +194,7 @@ __device__ __forceinline__ void gemm8p_epilogue(const Epi8p& e, bool has_aux, bo
       u32x4 q[2][4];
       auto request = [&](int ch, u32x4 (&dst)[4]) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(e.res, vcr[r], MISSM_SC(ch >> 2, ch & 3), 0);
+        for (int r = 0; r < 4; ++r) dst[r] = __builtin_amdgcn_raw_buffer_load_b128(e.res, vcr[r], MISSM_SC(ch >> 2, ch & 3), MISSM_EPI_LOAD_AUX);
       };
       request(0, q[0]);
 #pragma unroll

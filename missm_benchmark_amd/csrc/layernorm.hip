@@ -53,7 +53,9 @@ __device__ __forceinline__ void ln_fwd_body(const LnFwdArgs& a, int bx, int gx) 
 #pragma unroll
     for (int c = 0; c < CH; ++c) {
       const int col = (c * 64 + lane) * 4;
-      nv[c] = col < a.cols ? load4(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
+      // (the residual stream is read once here and next by this LayerNorm's backward, a whole step later: streaming load -
+      //  64.56 / 64.38 / 64.39 vs 64.81 / 64.63 / 64.55 ms per step with both LayerNorm kernels on it, alternating runs)
+      nv[c] = col < a.cols ? load4_nt(xr + col) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
   };
   issue(row0);
@@ -170,7 +172,7 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) 
     for (int c = 0; c < CH; ++c) {
       const int col = (c * 64 + lane) * 4;
       if ((FAST || col < a.cols)) {
-        nx[c] = load4(xr + col);
+        nx[c] = load4_nt(xr + col);            // (streamed: see the forward)
         ndy[c] = *reinterpret_cast<const DyRaw*>(dyr + col);
         if (FAST || a.accumulate) nprev[c] = load4(pr + col);
       }
