@@ -44,6 +44,10 @@ constexpr int attn_waves(int ntp) { (void)ntp; return ANW; }
 constexpr float kNegInf = -__builtin_huge_valf();
 
 __device__ __attribute__((aligned(16))) unsigned int g_attn_zero16[4];   // source of zero-filled LDS chunks
+// cache policy of the head-slice stagings (a (sequence, head) slice is read by one workgroup, once per pass): 0 default, 2 = nt
+#ifndef MISSM_ATTN_LOAD_AUX
+#define MISSM_ATTN_LOAD_AUX 0
+#endif
 
 // stage L rows (zero-filled up to LP) of one head's [L, 64] slice into a swizzled LDS tile with global_load_lds:
 // every 1-KiB piece is one wave instruction, all pieces of the tile are in flight together (no VGPR round trip);
@@ -59,7 +63,7 @@ __device__ __forceinline__ void stage_head(char* lds, const T* src, size_t base,
     const int row = pi * RPP + lane / NC, c = (lane % NC) ^ (row & M);
     const T* p = (row < L) ? src + (base + (size_t)row * tok_stride) * ld + col0 + c * EPC
                            : reinterpret_cast<const T*>(g_attn_zero16);
-    __builtin_amdgcn_global_load_lds((gptr)p, (lptr)(lds + pi * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr)p, (lptr)(lds + pi * 1024), 16, 0, MISSM_ATTN_LOAD_AUX);
   }
 }
 template <bool PW> __device__ __forceinline__ void stage_wait() {
