@@ -265,12 +265,8 @@ __device__ __forceinline__ int gemm8p_store_tile(const GemmArgs& g, const f32x4 
   // saveexec, the operation, loop: 195 of them in the 8-phase kernel since round 2 made its grid resident - found in the .s in round 3).
   auto uptr = [](const void* p) {
     const unsigned long long v = reinterpret_cast<unsigned long long>(p);
-#ifdef MISSM_X_WATERFALL
-    return reinterpret_cast<char*>(v);
-#else
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return reinterpret_cast<char*>(((unsigned long long)hi << 32) | lo);
-#endif
   };
   mwb = __builtin_amdgcn_readfirstlane(mwb);
   Epi8p e;
@@ -295,10 +291,11 @@ __device__ __forceinline__ int gemm8p_store_tile(const GemmArgs& g, const f32x4 
 }
 
 // STAGGER: waves 4-7 run one barrier behind waves 0-3.
-// The grid is PERSISTENT (one workgroup per CU walks tiles bid, bid + gridDim.x, ...): once a tile's main loop has ended every
-// LDS slot is free, so the next tile's first seven half tiles are requested BEFORE this tile's epilogue - their 1.5-2.4 us of
-// latency (in-kernel stamps) and the workgroup relaunch hide under the stores.  vmcnt is in issue order: the epilogue's own
-// loads / stores are younger than those requests, so the counted wait at the top of the next tile covers them.
+// The grid can be RESIDENT (one workgroup per CU walks tiles: statically b, b + gridDim.x, ... or drawn from the per-XCD queues below):
+// once a tile's main loop has ended every LDS slot is free, so the next tile's first seven half tiles are requested BEFORE this tile's
+// epilogue - their 1.5-2.4 us of latency (in-kernel stamps) and the workgroup relaunch hide under the stores.  vmcnt is in issue order:
+// the epilogue's own loads / stores are younger than those requests and are COUNTED into the wait at the top of the next tile
+// (vmcnt(6 + operations): the stores stay in flight across it).
 template <bool STAGGER>
 __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   extern __shared__ __attribute__((aligned(16))) char lds[];   // 8 slots x 16 KiB; slot = (4 * (K tile & 1) + h), h: B0 A0 B1 A1
@@ -372,14 +369,10 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   // tile's fourteen requests.  An inline-assembly atomic is no way out either: the compiler copies its output register while the
   // value is still in flight - tiles were drawn twice and skipped.)
   unsigned drawn = 0;
-#ifdef MISSM_X_OLDDRAW
-  if (dyn && tid == 0) drawn = __hip_atomic_fetch_add(gall.sched + qx, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
   if (dyn) {
     const __amdgpu_buffer_rsrc_t qr = __builtin_amdgcn_make_buffer_rsrc(gall.sched + qx, 0, 4, 0x00020000);
     drawn = (unsigned)__builtin_amdgcn_raw_ptr_buffer_atomic_add_i32(1, qr, tid == 0 ? 0 : 64, 0, 0);
   }
-#endif
   f32x4 bias4 = prefetch_bias(g, n0 + wc * 64, 0, lane);
   f32x4 acc[2][2][4][2];                     // [A half][B half][16-row tile][16-column tile]
 #pragma unroll
@@ -395,9 +388,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   // tiles AND the epilogue's stores stay in flight (round 2 waited vmcnt(6) here, i.e. for every store of the epilogue to be
   // acknowledged: that wait was the persistent grid's whole loss against a relaunch).  The counter holds 6 bits: 63 is still a
   // lower bound on what is younger than K tile 0 when epi_ops = 64.
-#ifdef MISSM_X_TOPDRAIN
-  if (epi_ops != 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else
-#endif
   if (epi_ops == 16) asm volatile("s_waitcnt vmcnt(22)" ::: "memory");
   else if (epi_ops == 32) asm volatile("s_waitcnt vmcnt(38)" ::: "memory");
   else if (epi_ops == 48) asm volatile("s_waitcnt vmcnt(54)" ::: "memory");
@@ -493,9 +483,7 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
 #undef MISSM_8P_FENCE_ALL
   // (the compiler waits for the bias vector at its first use; in the epilogue that wait was vmcnt(0) - behind the next tile's fourteen
   //  requests.  Using it here, where nothing but dropped requests is pending, leaves the epilogue without that wait.)
-#ifndef MISSM_X_NOBIASASM
   asm volatile("" : "+v"(bias4));
-#endif
   if (dyn) {                                 // the draw went out a whole main loop ago: hand it to the other waves through LDS
     using ldsw = volatile __attribute__((address_space(3))) unsigned*;
     if (tid == 0) *(ldsw)(lds + 131072) = drawn;
@@ -510,9 +498,6 @@ __global__ __launch_bounds__(512, 2) void gemm8p_kernel(GemmArgs gall) {
   bool more;                                 // wave-uniform
   if (dyn) {
     using ldsw = volatile __attribute__((address_space(3))) unsigned*;
-#ifdef MISSM_X_PREDRAIN
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     const unsigned d = __builtin_amdgcn_readfirstlane(*(ldsw)(lds + 131072));
     const int k = q_wgs + (int)d;            // queue entry (entries 0 .. q_wgs - 1 were the static first tiles)
     more = k < q_cnt;
