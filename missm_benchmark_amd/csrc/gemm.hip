@@ -1101,7 +1101,8 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
   // ... and the UNGROUPED products with K <= 1024 and N <= 1024 (the video tower's out-projections and their dX: three tile columns, an
   // epilogue-heavy K = 768 main loop): on the big lane alone the 256x128 kernel pays inside the two-stream step too, +0.6 %
   // (456.8 vs 454.1 samples/s, three alternating runs) - it was putting the small towers' grouped launches on it that cost.
-  const bool out4w = tail4w && ngroups <= 1 && !g_row_remainder && K <= 1024 && N <= 1024;
+  static const int out4w_env = getenv("MISSM_GEMM_OUT4W") ? atoi(getenv("MISSM_GEMM_OUT4W")) : 1;
+  const bool out4w = out4w_env && tail4w && ngroups <= 1 && !g_row_remainder && K <= 1024 && N <= 1024;
   const bool remainder4w = (tail4w && g_row_remainder && ngroups <= 1) || small4w || out4w;
   const bool rule4w = remainder4w || use4w == 1 || (use4w == 2 && K <= 1024) || (use4w == 3 && (ngroups > 1 || (K <= 1024 && N <= 1024)));
   if (rule4w && dtype == kBF16 && !trans_a && !trans_b && splitk == 1 && g.vec_ok && N % 64 == 0 && !accumulate && K % 64 == 0 && K >= 128 &&
