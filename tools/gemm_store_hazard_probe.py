@@ -1,5 +1,9 @@
+"""Every element of one fc2-shaped NT product with bias + fp32 residual against fp32 torch, three launches: lists wrong elements by
+tile / row in tile / column in tile and the terms of one of them.  Written to find the store-data hazard of DESIGN.md 4.1 (a 16-byte
+buffer store whose soffset is a REGISTER may have its first data register rewritten by the next instruction: component 0 of rows
+r = 0..2, lanes 12-15 of every 16, in tiles here and there - a 600-row spot check passes)."""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from missm_benchmark_amd import ops
 dt = torch.bfloat16
