@@ -13,6 +13,7 @@ instantiations.  The backward is hand-written (no autograd inside a tower): one 
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import List, Optional, Tuple
@@ -544,6 +545,9 @@ class ClipTower(nn.Module):
 # fill the chip like one long tower (their own 128x128 grids fill 59-88 % of it and run at ~480 TFLOP/s against ~1000 for the
 # video tower's).  With one lane this is exactly the single-tower path.
 # ======================================================================================================================
+_SPARSE_LAST = os.environ.get("MISSM_SPARSE_LAST", "1") != "0"   # 0: the last layer's backward runs on all rows (A/B, debugging)
+
+
 def _linear_bwd_lanes(lanes, dys, xs, wts, g_ws, g_bs, rows, dx_outs=None, act=ops.ACT_NONE, aux_ins=None, lora_sites=None):
     """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result STORED
     into the fp32 gradient - or ADDED to it when this backward accumulates, ClipTower._begin_backward); db += colsum(dy) riding
@@ -809,24 +813,48 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
         dh.append(dhg)
     dact = ops.ACT_GRAD[ops.ACT_CODE[c.hidden_act]]
     W = lambda key, which: [t._w(key)[which] for t in towers]            # noqa: E731
+    # only the pooled output carries a gradient (every training loop of the reference: `modality_encoder[key](**value)[1]`,
+    # languagebind/__init__.py:78): the residual gradient enters the last layer non-zero on the CLS rows only
+    cls_only = (_SPARSE_LAST and c.kind == "vision" and not t0.lora and all(dl is None for dl in d_lasts) and c.num_hidden_layers > 0)
     for i in reversed(range(c.num_hidden_layers)):
         L = [t._lp[i] for t in towers]
         # LoRA towers: per linear None (frozen: no dW) or its adapters (dW into scratch, then dA / dB); plain towers: None = the usual dW
         LS = (lambda key: [l.lora.get(key) for l in L]) if t0.lora else (lambda key: None)       # noqa: E731
         pfx = f"encoder.layers.{i}"
         recs = [states[g].layers[i] for g in G]
-        # ---- MLP block: h3 = h2 + fc2(act(fc1(LN2(h2))))
         h2, x2, m2, r2, u, a = (list(v) for v in zip(*[r.m for r in recs]))
-        du = E(rows, f, device=dev, dtype=T)
-        _linear_bwd_lanes(towers, dh_T, a, W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], rows, dx_outs=du, act=dact, aux_ins=u, lora_sites=LS("fc2"))
-        dx2 = E(rows, d, device=dev, dtype=T)
-        _linear_bwd_lanes(towers, du, x2, W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], rows, dx_outs=dx2, lora_sites=LS("fc1"))
-        ops.layernorm_bwd_lanes(dx2, h2, m2, r2, [l.ln2_w for l in L], dh, [l.g_ln2_w for l in L], [l.g_ln2_b for l in L], rows, d, dh_T)
-        # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
         hin, x1, m1, r1, qkv, ctx, lse = (list(v) for v in zip(*[r.a for r in recs]))
-        dctx_all = torch.empty(rows * len(towers), d, device=dev, dtype=T)
-        dctx = [dctx_all[g * rows:(g + 1) * rows] for g in G]
-        _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], rows, dx_outs=dctx, lora_sites=LS("out"))
+        if cls_only and i == c.num_hidden_layers - 1:
+            # The LAST layer's MLP block and out-projection see a gradient that is non-zero on the CLS rows only (the loss reads
+            # post_layernorm(h[:, 0]) and nothing else; LayerNorm, the MLP and the linears act row by row): their input / weight
+            # gradients are formed from the N = B * T CLS rows - strided views of the saved activations, no copies - instead of N * S
+            # rows of which all the others are exactly zero.  Same sums, 1 / S of the work: seven full-size GEMMs and a LayerNorm
+            # backward per tower and step (1.8 ms of kernel time at B = 32).  Behind the attention backward the gradient is dense.
+            cl = lambda t, w: t.view(N, S, w)[:, 0]          # noqa: E731  rows n * S of a [rows, w] buffer, row pitch S * w
+            dh_c = [cl(dh_T[g], d) for g in G]
+            du = E(N, f, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, dh_c, [cl(t, f) for t in a], W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], N,
+                              dx_outs=du, act=dact, aux_ins=[cl(t, f) for t in u])
+            dx2 = E(N, d, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, du, [cl(t, d) for t in x2], W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], N, dx_outs=dx2)
+            for g in G:     # LayerNorm 2 backward on the gathered rows: x, the running gradient and its compute-dtype copy at rows n * S
+                ops.layernorm_bwd(dx2[g], h2[g], m2[g].view(N, S)[:, 0].contiguous(), r2[g].view(N, S)[:, 0].contiguous(), L[g].ln2_w, dh[g],
+                                  L[g].g_ln2_w, L[g].g_ln2_b, N, d, accumulate=True, in_mul=S, dx_cast=dh_T[g])
+            dctx_all = torch.zeros(rows * len(towers), d, device=dev, dtype=T)
+            dctx = [dctx_all[g * rows:(g + 1) * rows] for g in G]
+            _linear_bwd_lanes(towers, dh_c, [cl(t, d) for t in ctx], W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], N,
+                              dx_outs=[cl(t, d) for t in dctx])
+        else:
+            # ---- MLP block: h3 = h2 + fc2(act(fc1(LN2(h2))))
+            du = E(rows, f, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, dh_T, a, W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], rows, dx_outs=du, act=dact, aux_ins=u, lora_sites=LS("fc2"))
+            dx2 = E(rows, d, device=dev, dtype=T)
+            _linear_bwd_lanes(towers, du, x2, W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], rows, dx_outs=dx2, lora_sites=LS("fc1"))
+            ops.layernorm_bwd_lanes(dx2, h2, m2, r2, [l.ln2_w for l in L], dh, [l.g_ln2_w for l in L], [l.g_ln2_b for l in L], rows, d, dh_T)
+            # ---- attention block: h2 = h + out(attn(qkv(LN1(h))))
+            dctx_all = torch.empty(rows * len(towers), d, device=dev, dtype=T)
+            dctx = [dctx_all[g * rows:(g + 1) * rows] for g in G]
+            _linear_bwd_lanes(towers, dh_T, ctx, W(f"{pfx}.out", 1), [l.g_out_w for l in L], [l.g_out_b for l in L], rows, dx_outs=dctx, lora_sites=LS("out"))
         if len(towers) > 1:      # one launch over every lane's sequences (forward_lanes made the saved buffers slices of one allocation)
             qkv_all, ctx_all, lse_all = recs[0].a_all
             dqkv_all = torch.empty(rows * len(towers), 3 * d, device=dev, dtype=T)
@@ -913,6 +941,10 @@ class _TowerFn(torch.autograd.Function):
     def forward(ctx, anchor, tower: ClipTower, inputs, need_grad, *params):
         state, last, pooled = tower._forward_impl(inputs, save=need_grad)
         ctx.tower, ctx.state, ctx.nparams = tower, state, len(params)
+        # an output nobody differentiates through arrives as None in backward, not as a materialised zero tensor: the training loops read
+        # the pooled output only, and a [N, S, d] fp32 zero gradient for last_hidden_state was 155 MB filled and copied per video step -
+        # and hid from backward_lanes that the gradient enters the last layer on the CLS rows only
+        ctx.set_materialize_grads(False)
         return last, pooled
 
     @staticmethod
@@ -940,6 +972,7 @@ class _TowerGroupFn(torch.autograd.Function):
     def forward(ctx, anchor, towers, inputs, need_grad):
         outs = forward_lanes(towers, inputs, save=need_grad)
         ctx.towers, ctx.states = towers, [o[0] for o in outs]
+        ctx.set_materialize_grads(False)     # (see _TowerFn.forward)
         flat = []
         for _, last, pooled in outs:
             flat += [last, pooled]

@@ -137,6 +137,40 @@ def test_vision_tower_vs_reference_fixture(pkg, name, dtype, tol):
         assert grad_ok(k, mine, g, gtol, dtype), k
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("name", ["vision_tiny", "video_tiny", "image_time_tiny", "patch_dropout_video_tiny", "vision_s197"])
+def test_last_layer_backward_on_cls_rows_equals_dense(pkg, name, dtype):
+    """When only the pooled output is differentiated (every training loop of the reference: `modality_encoder[key](**value)[1]`,
+    languagebind/__init__.py:78) the last layer's MLP / out-projection backward runs on the CLS rows alone (towers.backward_lanes);
+    a zero cotangent for last_hidden_state forces the all-rows path.  Same gradients: fp32 instantiation to 2e-5 of each tensor's scale
+    (summation order), bf16 to 2e-2 (the dense path rounds the same products in another order)."""
+    fix = load_golden(name)
+    ocfg = O.VisionCfg(**fix["cfg"])
+    params = fix.get("params") or O.init_tower_params(ocfg, fix["seed_w"])
+    x = vision_inputs(fix, ocfg).cuda()
+    kw = dict(patch_keep=fix["patch_keep"]) if "patch_keep" in fix else {}
+    grads = []
+    for dense in (False, True):
+        tower = make_tower(pkg, fix["cfg"], "vision", params, dtype)
+        if kw:
+            tower.train()
+        last, pooled = tower(x, **kw)
+        cp = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(5)).cuda()
+        loss = (pooled * cp).sum()
+        if dense:
+            loss = loss + (last * 0.0).sum()
+        loss.backward()
+        grads.append({k: p.grad.detach().float().cpu().clone() for k, p in tower.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 10
+    tol = 2e-5 if dtype == torch.float32 else 2e-2
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        if k.endswith("k_proj.bias"):        # an identically-zero gradient (see grad_ok): rounding noise on both paths
+            assert float((a - b).abs().max()) < (1e-5 if dtype == torch.float32 else 5e-3), k
+            continue
+        assert float((a - b).abs().max()) <= tol * float(b.abs().max().clamp_min(1e-12)) + 1e-12, k
+
+
 def test_full_size_vitb16_vs_reference_and_properties(pkg):
     """BASELINE.json configs[0] at full size on the GPU (ViT-B/16, 224x224, 197 tokens, B = 4): pooled output and a slice of
     the last hidden state against the fixture captured from the reference (fp32 instantiation 1e-3, bf16 3e-2), then the
