@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import nn as hnn
-from ..towers import ClipTower, TowerConfig, run_towers
+from ..towers import ClipTower, TowerConfig, pooled_output_only, run_towers
 
 LOGIT_SCALE_INIT = 2.6592  # configuration_image.py:303
 PROJECTION_DIM = 768       # train_ddp.py:31 feature_dims forces this
@@ -301,13 +301,15 @@ class LanguageBind(nn.Module):
         return hnn.l2norm_scale(emb, scale)
 
     def _embed(self, key, value):
-        return self._finish(key, self.modality_encoder[key](**value)[1])
+        with pooled_output_only():       # (only [1], the pooled output, is read: languagebind/__init__.py:78)
+            return self._finish(key, self.modality_encoder[key](**value)[1])
 
     def _embed_unit(self, keys, values):
         """one work unit: a single tower, or several shape-identical ones in lock-step (towers.run_towers)"""
         if len(keys) == 1:
             return {keys[0]: self._embed(keys[0], values[0])}
-        outs = run_towers([self.modality_encoder[k] for k in keys], values)
+        with pooled_output_only():
+            outs = run_towers([self.modality_encoder[k] for k in keys], values)
         return {k: self._finish(k, o[1]) for k, o in zip(keys, outs)}
 
     def _units(self, inputs):

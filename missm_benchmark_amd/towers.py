@@ -547,6 +547,24 @@ class ClipTower(nn.Module):
 # ======================================================================================================================
 _SPARSE_LAST = os.environ.get("MISSM_SPARSE_LAST", "1") != "0"   # 0: the last layer's backward runs on all rows (A/B, debugging)
 
+import contextlib
+import threading
+_POOLED = threading.local()
+
+
+@contextlib.contextmanager
+def pooled_output_only():
+    """Inside this context a vision tower's forward may leave `last_hidden_state` uncomputed (it is returned as None): the bundle
+    reads the pooled output only (`self.modality_encoder[key](**value)[1]`, languagebind/__init__.py:78), and the pooled output is
+    post_layernorm(h[:, 0]) - of the LAST layer's out-projection and MLP only the CLS rows are needed.  A tower called directly
+    (ClipTower.forward) always returns the full last_hidden_state."""
+    prev = getattr(_POOLED, "on", False)
+    _POOLED.on = True
+    try:
+        yield
+    finally:
+        _POOLED.on = prev
+
 
 def _linear_bwd_lanes(lanes, dys, xs, wts, g_ws, g_bs, rows, dx_outs=None, act=ops.ACT_NONE, aux_ins=None, lora_sites=None):
     """dW = dy^T x: TN GEMM reading dy / x where they lie (split-K slices summed by the library's reduce kernel, result STORED
@@ -674,6 +692,9 @@ def forward_lanes(towers, inputs, save: bool):
         ss[g].geom = (B, Tf, N, S, rows)
     act = ops.ACT_CODE[c.hidden_act]
     W = lambda key, which: [t._w(key)[which] for t in towers]            # noqa: E731
+    pooled_only = (getattr(_POOLED, "on", False) and _SPARSE_LAST and c.kind == "vision" and not t0.lora and c.num_hidden_layers > 0)
+    for g in G:
+        ss[g].pooled_only = pooled_only
     for i in range(c.num_hidden_layers):
         L = [t._lp[i] for t in towers]
         pfx = f"encoder.layers.{i}"
@@ -725,20 +746,38 @@ def forward_lanes(towers, inputs, save: bool):
             ops.attention_fwd(qkv_all, ctx_all, lse_all, N * len(towers), S, H, hd, causal=causal)
         else:
             ops.attention_fwd(qkv[0], ctx[0], lse[0], N, S, H, hd, causal=causal, key_mask=key_mask[0])
-        h2 = E(rows, d, **f32)
-        ops.gemm_grouped(ctx, W(f"{pfx}.out", 0), h2, bias=[l.out_b for l in L], resid=h)
-        x2 = E(rows, d, device=dev, dtype=T)
-        m2, r2 = E(rows, **f32), E(rows, **f32)
-        ops.layernorm_fwd_lanes(h2, [l.ln2_w for l in L], [l.ln2_b for l in L], x2, m2, r2, rows, d, c.layer_norm_eps)
-        a = E(rows, f, device=dev, dtype=T)
-        u = E(rows, f, device=dev, dtype=T) if save else None
-        ops.gemm_grouped(x2, W(f"{pfx}.fc1", 0), a, bias=[l.fc1_b for l in L], act=act, aux_out=u)
-        h3 = E(rows, d, **f32)
-        ops.gemm_grouped(a, W(f"{pfx}.fc2", 0), h3, bias=[l.fc2_b for l in L], resid=h2)
+        cls_fwd = pooled_only and i == c.num_hidden_layers - 1
+        if cls_fwd:
+            # last layer, pooled output only: out-projection, LayerNorm 2 and the MLP on the N = B * T CLS rows (rows n * S of the full
+            # buffers through strided views; the LayerNorm / MLP operands compact [N, .]); the other rows of h2 / h3 stay unwritten
+            cl = lambda t, w: t.view(N, S, w)[:, 0]          # noqa: E731
+            h2 = E(rows, d, **f32)
+            ops.gemm_grouped([cl(t, d) for t in ctx], W(f"{pfx}.out", 0), [cl(t, d) for t in h2], bias=[l.out_b for l in L], resid=[cl(t, d) for t in h])
+            x2 = E(N, d, device=dev, dtype=T)
+            m2, r2 = E(N, **f32), E(N, **f32)
+            for g in G:
+                ops.layernorm_fwd(h2[g], L[g].ln2_w, L[g].ln2_b, x2[g], m2[g], r2[g], N, d, c.layer_norm_eps, in_mul=S)
+            a = E(N, f, device=dev, dtype=T)
+            u = E(N, f, device=dev, dtype=T) if save else None
+            ops.gemm_grouped(x2, W(f"{pfx}.fc1", 0), a, bias=[l.fc1_b for l in L], act=act, aux_out=u)
+            h3 = E(rows, d, **f32)
+            ops.gemm_grouped(a, W(f"{pfx}.fc2", 0), [cl(t, d) for t in h3], bias=[l.fc2_b for l in L], resid=[cl(t, d) for t in h2])
+        else:
+            h2 = E(rows, d, **f32)
+            ops.gemm_grouped(ctx, W(f"{pfx}.out", 0), h2, bias=[l.out_b for l in L], resid=h)
+            x2 = E(rows, d, device=dev, dtype=T)
+            m2, r2 = E(rows, **f32), E(rows, **f32)
+            ops.layernorm_fwd_lanes(h2, [l.ln2_w for l in L], [l.ln2_b for l in L], x2, m2, r2, rows, d, c.layer_norm_eps)
+            a = E(rows, f, device=dev, dtype=T)
+            u = E(rows, f, device=dev, dtype=T) if save else None
+            ops.gemm_grouped(x2, W(f"{pfx}.fc1", 0), a, bias=[l.fc1_b for l in L], act=act, aux_out=u)
+            h3 = E(rows, d, **f32)
+            ops.gemm_grouped(a, W(f"{pfx}.fc2", 0), h3, bias=[l.fc2_b for l in L], resid=h2)
         if save:
             for g in G:
                 recs[g].a = (h[g], x1[g], m1[g], r1[g], qkv[g], ctx[g], lse[g])
                 recs[g].m = (h2[g], x2[g], m2[g], r2[g], u[g], a[g])
+                recs[g].cls = cls_fwd            # the MLP block's saved operands are compact [N, .] (CLS rows)
                 recs[g].a_all = (qkv_all, ctx_all, lse_all) if g == 0 else None
                 ss[g].layers.append(recs[g])
         h = h3
@@ -757,7 +796,7 @@ def forward_lanes(towers, inputs, save: bool):
                 ops.mean_rows(pl, pooled, B, Tf, d)
             else:
                 pooled = pl
-            last = h[g].view(N, S, d)
+            last = None if pooled_only else h[g].view(N, S, d)      # (pooled only: the non-CLS rows of h were never computed)
             s.pool = (h[g], mp, rp, None, None, None) if save else None
         else:
             last = torch.empty(rows, d, **f32)
@@ -816,6 +855,8 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
     # only the pooled output carries a gradient (every training loop of the reference: `modality_encoder[key](**value)[1]`,
     # languagebind/__init__.py:78): the residual gradient enters the last layer non-zero on the CLS rows only
     cls_only = (_SPARSE_LAST and c.kind == "vision" and not t0.lora and all(dl is None for dl in d_lasts) and c.num_hidden_layers > 0)
+    if any(getattr(st_, "pooled_only", False) for st_ in states) and not cls_only:
+        raise RuntimeError("a pooled-output-only forward cannot be differentiated through last_hidden_state")
     for i in reversed(range(c.num_hidden_layers)):
         L = [t._lp[i] for t in towers]
         # LoRA towers: per linear None (frozen: no dW) or its adapters (dW into scratch, then dA / dB); plain towers: None = the usual dW
@@ -831,14 +872,17 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
             # rows of which all the others are exactly zero.  Same sums, 1 / S of the work: seven full-size GEMMs and a LayerNorm
             # backward per tower and step (1.8 ms of kernel time at B = 32).  Behind the attention backward the gradient is dense.
             cl = lambda t, w: t.view(N, S, w)[:, 0]          # noqa: E731  rows n * S of a [rows, w] buffer, row pitch S * w
+            compact = bool(getattr(recs[0], "cls", False))   # the forward ran this block on the CLS rows: its saved operands are [N, .]
+            cm = (lambda t, w: t) if compact else cl         # noqa: E731
+            cs = (lambda t: t) if compact else (lambda t: t.view(N, S)[:, 0].contiguous())     # noqa: E731  row statistics
             dh_c = [cl(dh_T[g], d) for g in G]
             du = E(N, f, device=dev, dtype=T)
-            _linear_bwd_lanes(towers, dh_c, [cl(t, f) for t in a], W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], N,
-                              dx_outs=du, act=dact, aux_ins=[cl(t, f) for t in u])
+            _linear_bwd_lanes(towers, dh_c, [cm(t, f) for t in a], W(f"{pfx}.fc2", 1), [l.g_fc2_w for l in L], [l.g_fc2_b for l in L], N,
+                              dx_outs=du, act=dact, aux_ins=[cm(t, f) for t in u])
             dx2 = E(N, d, device=dev, dtype=T)
-            _linear_bwd_lanes(towers, du, [cl(t, d) for t in x2], W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], N, dx_outs=dx2)
+            _linear_bwd_lanes(towers, du, [cm(t, d) for t in x2], W(f"{pfx}.fc1", 1), [l.g_fc1_w for l in L], [l.g_fc1_b for l in L], N, dx_outs=dx2)
             for g in G:     # LayerNorm 2 backward on the gathered rows: x, the running gradient and its compute-dtype copy at rows n * S
-                ops.layernorm_bwd(dx2[g], h2[g], m2[g].view(N, S)[:, 0].contiguous(), r2[g].view(N, S)[:, 0].contiguous(), L[g].ln2_w, dh[g],
+                ops.layernorm_bwd(dx2[g], h2[g], cs(m2[g]), cs(r2[g]), L[g].ln2_w, dh[g],
                                   L[g].g_ln2_w, L[g].g_ln2_b, N, d, accumulate=True, in_mul=S, dx_cast=dh_T[g])
             dctx_all = torch.zeros(rows * len(towers), d, device=dev, dtype=T)
             dctx = [dctx_all[g * rows:(g + 1) * rows] for g in G]

@@ -149,26 +149,36 @@ def test_last_layer_backward_on_cls_rows_equals_dense(pkg, name, dtype):
     params = fix.get("params") or O.init_tower_params(ocfg, fix["seed_w"])
     x = vision_inputs(fix, ocfg).cuda()
     kw = dict(patch_keep=fix["patch_keep"]) if "patch_keep" in fix else {}
-    grads = []
-    for dense in (False, True):
+    grads, pooleds = [], []
+    for mode in ("cls_backward", "dense", "pooled_only_forward"):
         tower = make_tower(pkg, fix["cfg"], "vision", params, dtype)
         if kw:
             tower.train()
-        last, pooled = tower(x, **kw)
+        if mode == "pooled_only_forward":
+            # what the bundle does (languagebind/__init__.py:78 reads [1] only): the last layer's out-projection / MLP FORWARD on the CLS
+            # rows as well, last_hidden_state left uncomputed
+            with pkg.towers.pooled_output_only():
+                last, pooled = tower(x, **kw)
+            assert last is None
+        else:
+            last, pooled = tower(x, **kw)
         cp = torch.randn(pooled.shape, generator=torch.Generator().manual_seed(5)).cuda()
         loss = (pooled * cp).sum()
-        if dense:
+        if mode == "dense":
             loss = loss + (last * 0.0).sum()
         loss.backward()
+        pooleds.append(pooled.detach().float().cpu())
         grads.append({k: p.grad.detach().float().cpu().clone() for k, p in tower.named_parameters() if p.grad is not None})
-    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 10
     tol = 2e-5 if dtype == torch.float32 else 2e-2
-    for k in grads[0]:
-        a, b = grads[0][k], grads[1][k]
-        if k.endswith("k_proj.bias"):        # an identically-zero gradient (see grad_ok): rounding noise on both paths
-            assert float((a - b).abs().max()) < (1e-5 if dtype == torch.float32 else 5e-3), k
-            continue
-        assert float((a - b).abs().max()) <= tol * float(b.abs().max().clamp_min(1e-12)) + 1e-12, k
+    assert torch.equal(pooleds[0], pooleds[1]) and rel(pooleds[2], pooleds[1]) < tol
+    for other in (0, 2):
+        assert grads[other].keys() == grads[1].keys() and len(grads[1]) > 10
+        for k in grads[1]:
+            a, b = grads[other][k], grads[1][k]
+            if k.endswith("k_proj.bias"):        # an identically-zero gradient (see grad_ok): rounding noise on every path
+                assert float((a - b).abs().max()) < (1e-5 if dtype == torch.float32 else 5e-3), k
+                continue
+            assert float((a - b).abs().max()) <= tol * float(b.abs().max().clamp_min(1e-12)) + 1e-12, (other, k)
 
 
 def test_full_size_vitb16_vs_reference_and_properties(pkg):
