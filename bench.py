@@ -373,7 +373,10 @@ def main():
                "config": {"workload": workload_name(modalities, args) + ": ViT-B/16 towers + sum fusion, fwd+bwd+allreduce+Adam", "per_gpu_batch": B, "global_batch": B * world,
                           "modalities": modalities, "missing_ratio": args.missing, "params": engine.num_parameters(),
                           "parallelism": f"dp{world}", "final_loss": round(final_loss, 4),
-                          "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG", "unset")},
+                          "HIP_FORCE_DEV_KERNARG": os.environ.get("HIP_FORCE_DEV_KERNARG", "unset"),
+                          # the loss reads the pooled output only: the last layer's out-projection / MLP (forward and backward) run on the
+                          # CLS rows, whose results are the only ones that reach the loss or any gradient (0 = all rows)
+                          "last_layer_on_cls_rows": os.environ.get("MISSM_SPARSE_LAST", "1") != "0"},
                "roofline": roof}
         if roof_attn is not None:
             out["roofline_attention"] = roof_attn
