@@ -108,7 +108,9 @@ int missm_layernorm_bwd(const void* dy, int dy_div, float dy_scale, const float*
 /* missm_layernorm_bwd (no row gather, dy_div 1) that also accumulates GROUP SUMS of the updated dx rows:
  * gsum[(row / gs_div) % gs_mod][:] += dx[row][:] (atomics; caller zeroes), rows = frames x gs_div.  Replaces the separate column-sum
  * pass of the temporal-embedding gradient: `hidden_states + self.temporal_embedding[:, :t, :]` (image/modeling_image.py:114-116) puts
- * d temporal_embedding[t] = sum over (b, n) of the residual gradient behind temporal_layer_norm1 (gs_div = S tokens, gs_mod = T). */
+ * d temporal_embedding[t] = sum over (b, n) of the residual gradient behind temporal_layer_norm1 (gs_div = S tokens, gs_mod = T).
+ * gs_div = 0 selects group = row % gs_mod: d position_embedding[s] = sum over frames of the gradient behind pre_layrnorm (gs_mod = S;
+ * `embeddings = embeddings + self.position_embedding(self.position_ids)`, third-party CLIPVisionEmbeddings / video/modeling_video.py:19-51). */
 int missm_layernorm_bwd_groupsum(const void* dy, float dy_scale, const float* x, const float* mean, const float* rstd,
                                  const float* gamma, float* dx, int accumulate, float* dgamma, float* dbeta, void* dx_cast,
                                  float* gsum, int gs_div, int gs_mod, int rows, int cols, int dy_dtype, void* stream);

@@ -137,6 +137,9 @@ struct LnBwdArgs {
   // group), which used to be a separate column-sum pass over the 155 MB residual gradient.  Instantiated as GS: a wave then walks the
   // rows of ONE frame (workgroup = 4 waves of one frame, `gridDim.x * 4 / (rows / gs_div)` waves per frame) and carries one sum.
   float* gsum; int gs_div, gs_mod;
+  // gs_strided: group = row % gs_mod instead (members gs_mod rows apart): the position-embedding gradient behind pre_layrnorm -
+  // d position_embedding[s] = sum over frames of dx[n, s, :] (class_embedding's gradient is row 0 of the same sums)
+  int gs_strided;
 };
 
 // FAST: cols == CH * 256, accumulate, dx_cast and no row gather - the residual-stream LayerNorms of every tower layer.  With the
@@ -182,9 +185,16 @@ __device__ __forceinline__ void ln_bwd_body(const LnBwdArgs& a, int bx, int gx) 
   int row0 = bx * 4 + wave, rstep = gx * 4, rend = a.rows, grp = 0;
   f32x4 asum[GS ? CH : 1];
   if constexpr (GS) {
-    const int wpf = (gx * 4) / (a.rows / a.gs_div);           // waves per frame (host: an exact multiple of 4)
-    const int w = bx * 4 + wave, f = w / wpf;
-    row0 = f * a.gs_div + (w - f * wpf); rstep = wpf; rend = (f + 1) * a.gs_div; grp = f % a.gs_mod;
+    const int w = bx * 4 + wave;
+    if (a.gs_strided) {                                       // group = token index: rows f, f + gs_mod, ... dealt over wpf waves
+      const int wpf = (gx * 4) / a.gs_mod;
+      const int f = w / wpf;
+      row0 = f + (w - f * wpf) * a.gs_mod; rstep = wpf * a.gs_mod; rend = a.rows; grp = f;
+    } else {
+      const int wpf = (gx * 4) / (a.rows / a.gs_div);         // waves per frame (host: an exact multiple of 4)
+      const int f = w / wpf;
+      row0 = f * a.gs_div + (w - f * wpf); rstep = wpf; rend = (f + 1) * a.gs_div; grp = f % a.gs_mod;
+    }
 #pragma unroll
     for (int c = 0; c < CH; ++c) asum[c] = f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -323,10 +333,12 @@ static int layernorm_bwd_core(const void* dy, int dy_div, float dy_scale, const 
                               int dy_dtype, void* stream) {
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd: cols must be a positive multiple of 4");
   LnBwdArgs a{dy, dy_div > 0 ? dy_div : 1, dy_scale, x, in_mul > 0 ? in_mul : 1, in_off, mean, rstd, gamma, dx, accumulate,
-              dgamma, dbeta, rows, cols, dx_cast, gsum, gs_div, gs_mod};
+              dgamma, dbeta, rows, cols, dx_cast, gsum, gs_div > 0 ? gs_div : 1, gs_mod, gs_div == 0 ? 1 : 0};
   if (gsum) {
-    MISSM_CHECK_ARG(gs_div > 0 && gs_mod > 0 && rows % gs_div == 0 && !in_off && a.in_mul == 1, "layernorm_bwd: group sums need rows = frames x gs_div, no row gather");
-    const int frames = rows / gs_div;
+    const bool strided = gs_div == 0;              // gs_div = 0: group = row % gs_mod
+    MISSM_CHECK_ARG(gs_div >= 0 && gs_mod > 0 && (strided ? rows % gs_mod == 0 : rows % gs_div == 0) && !in_off && a.in_mul == 1,
+                    "layernorm_bwd: group sums need rows = frames x gs_div (or a multiple of gs_mod), no row gather");
+    const int frames = strided ? gs_mod : rows / gs_div;
     const int wpf = frames <= 1024 ? 8 : 4;        // waves per frame (video tower at B = 32: 256 frames x 8 = the 512-workgroup grid)
     dim3 grid(frames * wpf / 4), block(256);
     hipStream_t s = static_cast<hipStream_t>(stream);
@@ -402,7 +414,7 @@ extern "C" int missm_layernorm_bwd_grouped(int ngroups, const void* const* dy, c
                                            float* const* dbeta, void* const* dx_cast, int rows, int cols, int dy_dtype, void* stream) {
   MISSM_CHECK_ARG(ngroups >= 1 && ngroups <= LN_MAX_GROUPS && dy && x && mean && rstd && gamma && dx && dx_cast, "layernorm_bwd_grouped: 1..8 groups");
   MISSM_CHECK_ARG(rows > 0 && cols > 0 && cols % 4 == 0, "layernorm_bwd_grouped: cols must be a positive multiple of 4");
-  LnBwdArgs a{nullptr, 1, 1.0f, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, rows, cols, nullptr, nullptr, 1, 1};
+  LnBwdArgs a{nullptr, 1, 1.0f, nullptr, 1, nullptr, nullptr, nullptr, nullptr, nullptr, 1, nullptr, nullptr, rows, cols, nullptr, nullptr, 1, 1, 0};
   LnBwdGroups gs;
   for (int g = 0; g < ngroups; ++g) {
     gs.dy[g] = dy[g]; gs.x[g] = x[g]; gs.mean[g] = mean[g]; gs.rstd[g] = rstd[g]; gs.gamma[g] = gamma[g]; gs.dx[g] = dx[g];

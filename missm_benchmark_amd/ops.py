@@ -192,7 +192,8 @@ def layernorm_fwd(x, gamma, beta, y, mean, rstd, rows, cols, eps, *, add=None, a
 
 def layernorm_bwd(dy, x, mean, rstd, gamma, dx, dgamma, dbeta, rows, cols, *, accumulate=True, dy_div=1, dy_scale=1.0,
                   in_mul=1, in_off=None, dx_cast=None, gsum=None, gs_div=1, gs_mod=1):
-    """gsum (fp32 [gs_mod, cols], caller zeroes): gsum[(row // gs_div) % gs_mod] += the updated dx rows, in the same pass"""
+    """gsum (fp32 [gs_mod, cols], caller zeroes): gsum[(row // gs_div) % gs_mod] += the updated dx rows, in the same pass;
+    gs_div = 0: gsum[row % gs_mod] instead"""
     if dx_cast is not None and dx_cast.dtype != dy.dtype:
         raise _lib.MissmError("layernorm_bwd: dx_cast must have dy's dtype")
     if gsum is not None:

@@ -952,11 +952,20 @@ def backward_lanes(towers, states, d_lasts, d_pooleds):
             U, x0, m0, r0, off, _ = s.emb
             # (PatchDropout: the gradient is scattered back to the kept tokens' embedding rows, the dropped ones get zero)
             dx = torch.empty(rows, d, **f32) if off is None else torch.zeros(N * S0, d, **f32)
-            ops.layernorm_bwd(dh[g], x0, m0, r0, st.view("pre_layrnorm.weight"), dx, gv("pre_layrnorm.weight"), gv("pre_layrnorm.bias"),
-                              rows, d, accumulate=False, in_off=off)
-            # position-embedding gradient: sum over frames of dx[n, s, :] = a plain column sum of dx viewed as [N, S0*d]
-            ops.colsum(dx.view(N, S0 * d), gv("embeddings.position_embedding.weight").view(S0 * d), R=N)
-            ops.colsum(dx.view(N, S0 * d)[:, :d], gv("embeddings.class_embedding"), R=N)
+            if off is None:
+                # position-embedding gradient = sum over frames of dx[n, s, :]: group sums (group = row % S) riding in this LayerNorm
+                # backward instead of two column-sum passes over dx; class_embedding's gradient is row 0 of the same sums
+                psum = torch.zeros(S0, d, **f32)
+                ops.layernorm_bwd(dh[g], x0, m0, r0, st.view("pre_layrnorm.weight"), dx, gv("pre_layrnorm.weight"), gv("pre_layrnorm.bias"),
+                                  rows, d, accumulate=False, gsum=psum, gs_div=0, gs_mod=S0)
+                gv("embeddings.position_embedding.weight").view(S0, d).add_(psum)
+                gv("embeddings.class_embedding").add_(psum[0])
+            else:
+                ops.layernorm_bwd(dh[g], x0, m0, r0, st.view("pre_layrnorm.weight"), dx, gv("pre_layrnorm.weight"), gv("pre_layrnorm.bias"),
+                                  rows, d, accumulate=False, in_off=off)
+                # position-embedding gradient: sum over frames of dx[n, s, :] = a plain column sum of dx viewed as [N, S0*d]
+                ops.colsum(dx.view(N, S0 * d), gv("embeddings.position_embedding.weight").view(S0 * d), R=N)
+                ops.colsum(dx.view(N, S0 * d)[:, :d], gv("embeddings.class_embedding"), R=N)
             ops.cast_rows(dx, dpe[g], N * P, d, rdiv=P, roff=1)
             Us.append(U)
         gwp = []

@@ -362,6 +362,26 @@ def test_layernorm_bwd_group_sums(ops, idt, B, T, S, d, cast):
     assert rel(gs2[:T], gs[:T]) < 1e-4
 
 
+@pytest.mark.parametrize("idt", DTYPES)
+@pytest.mark.parametrize("N,S,d", [(256, 197, 768), (6, 5, 64), (40, 33, 256)])
+def test_layernorm_bwd_group_sums_by_token(ops, idt, N, S, d):
+    """gs_div = 0: group = row % S - the position-embedding gradient (sum over frames of the gradient behind pre_layrnorm, whose row 0
+    is class_embedding's gradient) riding in that LayerNorm's backward; overwrite form (accumulate = False), fp32 and bf16 dy."""
+    rows = N * S
+    x, g = rnd(rows, d, seed=1), 1 + 0.1 * rnd(d, seed=2)
+    dy = q(rnd(rows, d, seed=4), idt)
+    xr, gr, br = x.clone().requires_grad_(True), g.clone().requires_grad_(True), torch.zeros(d, requires_grad=True)
+    F.layer_norm(xr, (d,), gr, br, 1e-5).backward(dy)
+    mean, rstd = x.mean(1), (x.var(1, unbiased=False) + 1e-5).rsqrt()
+    dx = torch.full((rows, d), 3.0, device="cuda")               # overwritten
+    gs = torch.zeros(S, d, device="cuda")
+    dg, db = torch.zeros(d, device="cuda"), torch.zeros(d, device="cuda")
+    ops.layernorm_bwd(dev(dy, idt), dev(x), dev(mean), dev(rstd), dev(g), dx, dg, db, rows, d, accumulate=False, gsum=gs, gs_div=0, gs_mod=S)
+    assert rel(dx, xr.grad) < 2e-5
+    assert rel(dg, gr.grad) < 1e-4 and rel(db, br.grad) < 1e-4
+    assert rel(gs, xr.grad.view(N, S, d).sum(0)) < 1e-4
+
+
 # ------------------------------------------------------------------ attention
 def attn_ref(qkv, nseq, L, H, hd, rowidx, causal, key_mask):
     """fp32 reference on gathered rows: returns out rows and a function giving d(qkv) for a cotangent"""
