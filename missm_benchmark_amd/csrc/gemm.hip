@@ -413,12 +413,7 @@ __global__ __launch_bounds__(64 * WG * WG, WG == 4 ? 4 : (RBK == 128 ? 2 : 4)) v
   const int wm = wave / WG, wn = wave % WG;
 
   const int ntiles = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
-  if (g.ngroups > 1) {                     // grouped launch (split-K off): workgroups [gi * ntiles, ...) work on group gi's operands
-    const int gi = bid / ntiles;
-    bid -= gi * ntiles;
-    select_group(g, g, gi);
-  }
+  const int bid = blockIdx.x;
   const int split = bid / ntiles;
   const int logical = xcd_remap(bid - split * ntiles, ntiles);
   int tm, tn;
@@ -1080,8 +1075,7 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
     hipLaunchKernelGGL(splitk_reduce8p_kernel, dim3(g.ngroups * t2 * 16), dim3(512), 0, s, g);
     return missm_check_launch("gemm8p_tn");
   }
-  // (grouped k-major products without split-K take the grouped form of the 128x128 kernel at the end)
-  if (ngroups > 1 && (trans_a || trans_b) && splitk != 1) return MISSM_GROUPED_UNAVAILABLE;
+  if (ngroups > 1 && (trans_a || trans_b)) return MISSM_GROUPED_UNAVAILABLE;
   // ---- 256x128 tile, 4 waves, two workgroups per CU (gemm4w.h) - OPT-IN.  Measured inside the step against the 8-phase kernel
   // (profiles/r02_gemm_insitu_8p_vs_4w.txt, one stream): it wins where the 256x256 grid leaves partial rounds or the epilogue
   // weighs most - every grouped launch of the four 197-token towers (N = 768: -8..-18 %, N = 2304 / 3072: 0..-6 %) and the video
@@ -1244,10 +1238,7 @@ static int gemm_core(const void* A, const void* B, void* C, int M, int N, int K,
       return missm_check_launch("gemm256");
     }
   }
-  // grouped launch of the 128x128 kernel [r3]: the tile-sized products of the last layer's CLS rows (four towers x 32 rows) were four
-  // launches of 6 - 24 tiles each per linear; workgroups [gi * tiles, ...) take group gi's operands.  Split-K stays one problem per launch.
-  if (ngroups > 1 && splitk != 1) return MISSM_GROUPED_UNAVAILABLE;
-  if (ngroups > 1) grid = dim3(tiles * ngroups);
+  if (ngroups > 1) return MISSM_GROUPED_UNAVAILABLE;
   // (a 32-deep K tile with 4 workgroups per CU was measured too: -3..20 % once the epilogue was compact; removed)
   // scheduling variant of the 128x128 kernel (measured, random data): s_setprio around the MFMA cluster is worth +4..10 % on
   // the K = 768 shapes; requesting all fragments of the K tile up front is worth +10 % at long K (968 vs 878 TFLOP/s at 4096^3)
